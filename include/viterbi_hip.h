@@ -1,0 +1,137 @@
+/*
+ * viterbi_hip.h -- C ABI of libviterbi_hip.so (MI355X / gfx950 Viterbi decoder).
+ *
+ * This is the drop-in boundary for the hot path of drwangxian/viterbi_spl: the
+ * float32 log-domain Viterbi forward recursion + argmax back-trace.  Plain
+ * pointers and sizes only; no torch types; no exceptions cross this ABI (every
+ * entry point returns a vit_status).  All device buffers are caller-owned; the
+ * library never allocates device memory and never synchronises the host inside
+ * vit_decode().
+ *
+ * Reference interfaces replaced (paths relative to the reference repo):
+ *   - viterbi_numba.core(B, prob_init, probs) -> int64[T]
+ *       dcnet/aot_viterbi_core.py:8-54, call site dcnet/tf_viterbi_decoding.py:147-151
+ *       ('i8[:](f4[:, ::1], f4[:], f4[:, ::1])': B is [S,S] "target <- source",
+ *        C-contiguous; probs is [T,S] C-contiguous).
+ *   - viterbi_librosa_fn(*, log_transition_matrix_T, log_prob_init, log_probs_st)
+ *       imm/tf_viterbi.py:75-109 (the log-domain core this ABI mirrors).
+ *   - the in-class copies Viterbi.viterbi_librosa_fn / SoftMaxViterbi.viterbi_librosa_fn
+ *       tonet/for_paper.py:1833-1870, :1999-2037 (after their host-side log step).
+ *
+ * Differences from the reference boundary, all deliberate:
+ *   - inputs are NEVER mutated (the Numba core logs its arguments in place,
+ *     dcnet/aot_viterbi_core.py:23-25);
+ *   - the contract starts at log-domain tensors: the prob -> log step stays on
+ *     the host in the Python adapters, because NumPy's float32 log is the one
+ *     operation whose last bit is not reproducible on a GPU;
+ *   - songs are batched ([B,T,S]) and may be ragged (lengths);
+ *   - states come back as int32 (the Python adapters widen to int64);
+ *   - the terminal log-likelihood delta_{T-1}[s_{T-1}] is returned as well
+ *     (the unused `p` at dcnet/tf_viterbi_decoding.py:255).
+ *
+ * NaN inputs are outside the contract.  -inf entries are accepted.
+ */
+#ifndef VITERBI_HIP_H_
+#define VITERBI_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIT_ABI_VERSION 1
+
+typedef enum vit_status {
+    VIT_OK = 0,
+    VIT_EINVAL = -1,       /* bad argument (null pointer, size out of range) */
+    VIT_ENOMEM = -2,       /* host allocation failed */
+    VIT_EHIP = -3,         /* a HIP runtime call failed (see vit_last_hip_error) */
+    VIT_EWORKSPACE = -4,   /* workspace smaller than vit_workspace_bytes() */
+    VIT_EUNSUPPORTED = -5, /* shape/algorithm combination not supported */
+    VIT_ENOTUPLOADED = -6  /* vit_decode() before vit_plan_upload() */
+} vit_status;
+
+/* storage type of the emission tensor (arithmetic is always float32) */
+typedef enum vit_dtype { VIT_F32 = 0, VIT_F16 = 1 } vit_dtype;
+
+/* forward-kernel selection */
+typedef enum vit_algo {
+    VIT_ALGO_AUTO = 0,   /* banded if the plan proved the structure, else dense */
+    VIT_ALGO_DENSE = 1,  /* S*S max-plus per frame, any matrix */
+    VIT_ALGO_BANDED = 2  /* exact row-constant + window + extra-column decomposition */
+} vit_algo;
+
+typedef struct vit_plan vit_plan; /* opaque: analysed transition matrix + prior */
+typedef void *vit_stream;         /* hipStream_t */
+
+typedef struct vit_plan_info {
+    int64_t S;
+    int32_t banded_ok;      /* 1 if the banded kernel may be used for this matrix */
+    int32_t n_consts;       /* distinct row constants */
+    int32_t n_extras;       /* extra exception columns shared by most rows */
+    int32_t max_window;     /* widest per-row exception window */
+    int32_t group_window;   /* window width the banded kernel evaluates per target */
+    int32_t reserved[3];
+    float consts[4];
+    int32_t extras[4];
+} vit_plan_info;
+
+int vit_abi_version(void);
+const char *vit_status_string(int status);
+/* last hipError_t seen by this library on the calling thread (0 = hipSuccess) */
+int vit_last_hip_error(void);
+
+/*
+ * Analyse a transition matrix on the host.
+ *   logA_T : host, [S,S] float32 C-order, row j = log-probabilities INTO target j
+ *            (same orientation the reference passes to its core,
+ *            dcnet/tf_viterbi_decoding.py:144, imm/tf_viterbi.py:77-80)
+ *   log_pi : host, [S] float32
+ * 1 <= S <= 1024.
+ */
+int vit_plan_create(const float *logA_T, const float *log_pi, int64_t S, vit_plan **out);
+void vit_plan_destroy(vit_plan *plan);
+int vit_plan_query(const vit_plan *plan, vit_plan_info *info);
+
+/* Device image of the plan: the caller allocates vit_plan_image_bytes() bytes of
+ * device memory (256-byte aligned) and uploads once; the copy is enqueued on `stream`. */
+size_t vit_plan_image_bytes(const vit_plan *plan);
+int vit_plan_upload(vit_plan *plan, void *device_image, size_t bytes, vit_stream stream);
+
+/* Bytes of device workspace vit_decode() needs for a [B,T,S] batch (back-pointers
+ * as uint16 + per-song terminals).  256-byte aligned base required. */
+size_t vit_workspace_bytes(const vit_plan *plan, int64_t B, int64_t T);
+
+/*
+ * Decode B songs.
+ *   logE      : device, [B,T,S] C-order, float32 or float16 (emis_dtype)
+ *   lengths   : device, [B] int64 or NULL; song b uses frames [0, clamp(lengths[b],1,T))
+ *   workspace : device, >= vit_workspace_bytes(plan,B,T)
+ *   states    : device, [B,T] int32; frames past a song's length are set to -1
+ *   loglik    : device, [B] float32 or NULL
+ * Enqueues kernels on `stream` and returns; no host synchronisation.
+ */
+int vit_decode(const vit_plan *plan, const void *logE, int emis_dtype, int64_t B, int64_t T,
+               const int64_t *lengths, void *workspace, size_t workspace_bytes,
+               int32_t *states, float *loglik, int algo, vit_stream stream);
+
+/* Forward pass only / back-trace only (same arguments); used by bench.py to time
+ * the two kernels separately.  vit_decode() == forward then backtrace. */
+int vit_forward(const vit_plan *plan, const void *logE, int emis_dtype, int64_t B, int64_t T,
+                const int64_t *lengths, void *workspace, size_t workspace_bytes,
+                float *loglik, int algo, vit_stream stream);
+int vit_backtrace(const vit_plan *plan, int64_t B, int64_t T, const int64_t *lengths,
+                  void *workspace, size_t workspace_bytes, int32_t *states, vit_stream stream);
+
+/* Fused epilogue of Viterbi.__call__ (tonet/for_paper.py:1828-1829):
+ * voiced = state < n_bins ; bins = min(state, n_bins-1).  n entries, device pointers.
+ * Negative states (ragged padding) give voiced = 0, bins = -1. */
+int vit_voicing_map(const int32_t *states, int64_t n, int32_t n_bins, uint8_t *voiced, int32_t *bins,
+                    vit_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITERBI_HIP_H_ */

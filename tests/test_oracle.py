@@ -1,0 +1,86 @@
+"""The oracle against the goldens generated from the imported reference (CPU only)."""
+import numpy as np
+import pytest
+
+from oracle import viterbi_oracle as vo
+from tests.common import case_emissions, case_params, sha
+
+
+def test_golden_inputs_regenerate_bit_exactly(golden):
+    for c in golden["manifest"]["log_cases"]:
+        if c["T"] > 1000:
+            continue
+        logA_T, log_pi = case_params(golden, c)
+        logE = case_emissions(c).numpy()
+        assert sha(logA_T, log_pi, logE) == c["sha256"], c
+
+
+def test_c_oracle_matches_reference_goldens(golden):
+    for c in golden["manifest"]["log_cases"]:
+        logA_T, log_pi = case_params(golden, c)
+        logE = case_emissions(c).numpy()
+        states, ll, delta = vo.decode_c(logA_T, log_pi, logE, return_delta=True)
+        k = c["index"]
+        assert np.array_equal(states, golden["data"][f"c{k}_states"].astype(np.int32)), c
+        assert delta.tobytes() == golden["data"][f"c{k}_delta"].tobytes(), c
+        assert np.float32(ll) == np.float32(c["loglik"])
+
+
+def test_numpy_oracle_matches_reference_goldens(golden):
+    for c in golden["manifest"]["log_cases"]:
+        if c["T"] > 1000:
+            continue
+        logA_T, log_pi = case_params(golden, c)
+        logE = case_emissions(c).numpy()
+        states, ll, delta = vo.decode_numpy(logA_T, log_pi, logE, return_delta=True)
+        k = c["index"]
+        assert states.dtype == np.int64
+        assert np.array_equal(states, golden["data"][f"c{k}_states"].astype(np.int64)), c
+        assert delta.tobytes() == golden["data"][f"c{k}_delta"].tobytes()
+
+
+def test_prob_domain_wrapper_matches_reference_goldens(golden):
+    A, pi = golden["params"]["msnet321_A"], golden["params"]["msnet321_pi"]
+    for c in golden["manifest"]["prob_cases"]:
+        k = c["index"]
+        got = vo.decode_probs_numpy(A, pi, golden["data"][f"p{k}_probs_st"])
+        assert np.array_equal(got, golden["data"][f"p{k}_states"].astype(np.int64))
+
+
+def test_batched_ragged_and_threads(golden):
+    c = next(c for c in golden["manifest"]["log_cases"] if c["params"] == "tonet361" and c["kind"] == "dense" and c["T"] == 1000)
+    logA_T, log_pi = case_params(golden, c)
+    from viterbi_spl_amd import synth
+    E = synth.emissions_dense(5, 300, 361, seed=9).numpy()
+    lengths = np.array([300, 1, 2, 177, 299], np.int64)
+    st, ll = vo.decode_c(logA_T, log_pi, E, lengths=lengths, threads=3)
+    for b in range(5):
+        s1, l1 = vo.decode_c(logA_T, log_pi, E[b, : lengths[b]])
+        assert np.array_equal(st[b, : lengths[b]], s1)
+        assert np.all(st[b, lengths[b]:] == -1)
+        assert ll[b] == l1
+
+
+def test_tie_break_is_lowest_index():
+    S, T = 8, 5
+    logA_T = np.zeros((S, S), np.float32)
+    log_pi = np.zeros(S, np.float32)
+    logE = np.zeros((T, S), np.float32)
+    st, ll = vo.decode_c(logA_T, log_pi, logE)
+    assert np.all(st == 0) and ll == 0.0
+    st2, _ = vo.decode_numpy(logA_T, log_pi, logE)
+    assert np.all(st2 == 0)
+
+
+def test_minus_inf_entries():
+    rng = np.random.default_rng(0)
+    S, T = 33, 40
+    logA_T = (-rng.integers(0, 64, (S, S)) / 8).astype(np.float32)
+    logA_T[rng.random((S, S)) < 0.5] = -np.inf
+    np.fill_diagonal(logA_T, 0.0)
+    log_pi = np.full(S, -np.inf, np.float32)
+    log_pi[3] = 0
+    logE = (-rng.integers(0, 64, (T, S)) / 8).astype(np.float32)
+    a, la = vo.decode_c(logA_T, log_pi, logE)
+    b, lb = vo.decode_numpy(logA_T, log_pi, logE)
+    assert np.array_equal(a, b) and la == lb and np.isfinite(la)

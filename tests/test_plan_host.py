@@ -1,0 +1,104 @@
+"""Plan analysis + exactness of the banded decomposition, on the CPU (no GPU needed)."""
+import numpy as np
+import pytest
+
+from oracle import viterbi_oracle as vo
+from tests.plan_replay import HostPlan, replay_banded, replay_dense_image
+from viterbi_spl_amd import synth
+
+
+def test_tonet_structure_is_proven(golden):
+    p = golden["params"]
+    plan = HostPlan(p["tonet361_logA_T"], p["tonet361_log_pi"])
+    assert plan.ok and plan.S == 361 and plan.SP == 384
+    assert plan.max_window == 29 and plan.W == 32
+    assert plan.extras == [360] and plan.dense_rows == [360]
+    assert plan.c0 == np.float32(synth.LOG_TINY32)
+    assert np.all(plan.lo[:361] + plan.W <= 361) and np.all(plan.lo[:361] >= 0)
+
+
+def test_msnet_real_parameters_are_banded(golden):
+    p = golden["params"]
+    plan = HostPlan(p["msnet321_logA_T"], p["msnet321_log_pi"])
+    assert plan.ok and plan.max_window == 25 and plan.W == 28
+    assert plan.extras == [320] and plan.dense_rows == [320]
+
+
+def test_unstructured_matrices_fall_back(golden):
+    p = golden["params"]
+    assert not HostPlan(p["dense361_logA_T"], p["dense361_log_pi"]).ok
+    assert not HostPlan(p["durrieu722_logA_T"], p["durrieu722_log_pi"]).ok
+    assert not HostPlan(p["dense97_logA_T"], p["dense97_log_pi"]).ok
+
+
+def test_image_packing_roundtrip(golden):
+    p = golden["params"]
+    A = p["dense97_logA_T"]
+    plan = HostPlan(A, p["dense97_log_pi"])
+    E = synth.emissions_dense(1, 50, 97, seed=2)[0].numpy()
+    a, la = replay_dense_image(plan, E)
+    b, lb = vo.decode_numpy(A, p["dense97_log_pi"], E)
+    assert np.array_equal(a, b) and la == lb
+    assert np.all(np.isneginf(plan.A4[:, 97:, :])) and np.all(np.isneginf(plan.log_pi[97:]))
+
+
+@pytest.mark.parametrize("pname,kind,T,seed", [
+    ("tonet361", "peaks", 120, 1), ("tonet361", "dense", 120, 2), ("tonet361", "ties", 120, 3),
+    ("msnet321", "peaks", 100, 4), ("msnet321", "ties", 100, 5),
+])
+def test_banded_replay_is_bit_exact(golden, pname, kind, T, seed):
+    from tests.common import GEN
+    p = golden["params"]
+    A, pi = p[f"{pname}_logA_T"], p[f"{pname}_log_pi"]
+    plan = HostPlan(A, pi)
+    E = GEN[kind](1, T, A.shape[0], seed=seed)[0].numpy()
+    st, ll, delta = replay_banded(plan, E)
+    ref, rl, rdelta = vo.decode_c(A, pi, E, return_delta=True)
+    assert np.array_equal(st, ref)
+    assert delta.tobytes() == rdelta.tobytes() and np.float32(ll) == np.float32(rl)
+
+
+def _banded_matrix(S, half, rng, extras=(), dense_rows=(), floor=-50.0, quant=4):
+    A = np.full((S, S), floor, np.float32)
+    for j in range(S):
+        lo, hi = max(0, j - half), min(S, j + half + 1)
+        A[j, lo:hi] = -(rng.integers(0, 40, hi - lo) / quant)
+    for x in extras:
+        A[:, x] = -(rng.integers(0, 40, S) / quant)
+    for r in dense_rows:
+        A[r, :] = -(rng.integers(0, 40, S) / quant)
+    return A.astype(np.float32)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_banded_structures_with_ties(seed):
+    """Adversarial: coarse value grid (many exact ties), extras in the middle, dense rows anywhere,
+    floor values that regularly win."""
+    rng = np.random.default_rng(seed)
+    S = int(rng.integers(70, 200))
+    half = int(rng.integers(1, 7))
+    extras = sorted(set(int(x) for x in rng.integers(0, S, int(rng.integers(0, 3)))))
+    dense_rows = sorted(set(int(x) for x in rng.integers(0, S, int(rng.integers(0, 3)))))
+    A = _banded_matrix(S, half, rng, extras, dense_rows, floor=-3.0 if seed % 2 else -50.0, quant=2)
+    pi = -(rng.integers(0, 8, S) / 2).astype(np.float32)
+    plan = HostPlan(A, pi)
+    assert plan.ok, (S, half, extras, dense_rows)
+    E = -(rng.integers(0, 6, (60, S)) / 2).astype(np.float32)
+    st, ll, delta = replay_banded(plan, E)
+    ref, rl, rdelta = vo.decode_c(A, pi, E, return_delta=True)
+    assert np.array_equal(st, ref)
+    assert delta.tobytes() == rdelta.tobytes()
+
+
+def test_banded_with_minus_inf_floor():
+    rng = np.random.default_rng(11)
+    S = 128
+    A = _banded_matrix(S, 3, rng, extras=(S - 1,), dense_rows=(S - 1,), floor=-np.inf)
+    pi = np.full(S, -np.inf, np.float32)
+    pi[5] = 0
+    plan = HostPlan(A, pi)
+    assert plan.ok
+    E = -(rng.integers(0, 6, (40, S)) / 2).astype(np.float32)
+    st, ll, delta = replay_banded(plan, E)
+    ref, rl, rdelta = vo.decode_c(A, pi, E, return_delta=True)
+    assert np.array_equal(st, ref) and delta.tobytes() == rdelta.tobytes()

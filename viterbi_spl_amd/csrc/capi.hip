@@ -1,0 +1,221 @@
+// capi.hip -- extern "C" entry points declared in include/viterbi_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/viterbi_hip.h"
+#include "kernels.hpp"
+#include "plan.hpp"
+
+struct vit_plan {
+    int S = 0;
+    vit::BandedPlan bp;
+    vit::ImageLayout L;
+    std::vector<uint8_t> host_image;
+    const uint8_t* dev_image = nullptr;
+};
+
+namespace {
+
+thread_local int g_last_hip_error = 0;
+
+inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+inline int psi_stride(int S) { return (S + 7) / 8 * 8; }
+
+int hip_fail(hipError_t e) {
+    g_last_hip_error = (int)e;
+    return VIT_EHIP;
+}
+
+struct WsLayout {
+    size_t off_psi, off_last, bytes;
+};
+
+WsLayout ws_layout(int S, int64_t B, int64_t T) {
+    WsLayout w;
+    w.off_psi = 0;
+    w.off_last = align256((size_t)B * (size_t)T * psi_stride(S) * sizeof(uint16_t));
+    w.bytes = w.off_last + align256((size_t)B * sizeof(int32_t));
+    return w;
+}
+
+int check_common(const vit_plan* plan, int64_t B, int64_t T, const void* ws, size_t ws_bytes) {
+    if (!plan || !ws) return VIT_EINVAL;
+    if (B < 0 || T < 1 || T > (int64_t)1 << 30 || B > (int64_t)1 << 30) return VIT_EINVAL;
+    if (!plan->dev_image) return VIT_ENOTUPLOADED;
+    if (ws_bytes < ws_layout(plan->S, B, T).bytes) return VIT_EWORKSPACE;
+    if (((uintptr_t)ws & 255) != 0) return VIT_EINVAL;
+    return VIT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vit_abi_version(void) { return VIT_ABI_VERSION; }
+
+const char* vit_status_string(int status) {
+    switch (status) {
+        case VIT_OK: return "ok";
+        case VIT_EINVAL: return "invalid argument";
+        case VIT_ENOMEM: return "out of host memory";
+        case VIT_EHIP: return "HIP runtime error";
+        case VIT_EWORKSPACE: return "workspace too small";
+        case VIT_EUNSUPPORTED: return "unsupported shape or algorithm";
+        case VIT_ENOTUPLOADED: return "plan image not uploaded";
+        default: return "unknown status";
+    }
+}
+
+int vit_last_hip_error(void) { return g_last_hip_error; }
+
+int vit_plan_create(const float* logA_T, const float* log_pi, int64_t S, vit_plan** out) {
+    if (!logA_T || !log_pi || !out) return VIT_EINVAL;
+    if (S < 1 || S > 1024) return VIT_EINVAL;
+    vit_plan* p = new (std::nothrow) vit_plan();
+    if (!p) return VIT_ENOMEM;
+    try {
+        p->S = (int)S;
+        p->bp = vit::analyze_banded(logA_T, (int)S);
+        p->L = vit::make_layout((int)S, p->bp);
+        p->host_image.resize(p->L.bytes);
+        vit::fill_image(logA_T, log_pi, p->bp, p->L, p->host_image.data());
+    } catch (const std::bad_alloc&) {
+        delete p;
+        return VIT_ENOMEM;
+    }
+    *out = p;
+    return VIT_OK;
+}
+
+void vit_plan_destroy(vit_plan* plan) { delete plan; }
+
+int vit_plan_query(const vit_plan* plan, vit_plan_info* info) {
+    if (!plan || !info) return VIT_EINVAL;
+    std::memset(info, 0, sizeof(*info));
+    info->S = plan->S;
+    info->banded_ok = plan->bp.ok ? 1 : 0;
+    info->n_consts = plan->bp.ok ? 1 : 0;
+    info->n_extras = plan->bp.n_extras;
+    info->max_window = plan->bp.max_window;
+    info->group_window = plan->bp.W;
+    info->reserved[0] = plan->bp.n_dense;
+    info->consts[0] = plan->bp.c0;
+    for (int k = 0; k < vit::kMaxExtras; ++k) info->extras[k] = k < plan->bp.n_extras ? plan->bp.extras[k] : -1;
+    return VIT_OK;
+}
+
+size_t vit_plan_image_bytes(const vit_plan* plan) { return plan ? plan->L.bytes : 0; }
+
+int vit_plan_upload(vit_plan* plan, void* device_image, size_t bytes, vit_stream stream) {
+    if (!plan || !device_image) return VIT_EINVAL;
+    if (bytes < plan->L.bytes || ((uintptr_t)device_image & 255) != 0) return VIT_EINVAL;
+    hipError_t e = hipMemcpyAsync(device_image, plan->host_image.data(), plan->L.bytes, hipMemcpyHostToDevice,
+                                  (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e);
+    plan->dev_image = static_cast<const uint8_t*>(device_image);
+    return VIT_OK;
+}
+
+size_t vit_workspace_bytes(const vit_plan* plan, int64_t B, int64_t T) {
+    if (!plan || B < 0 || T < 1) return 0;
+    return ws_layout(plan->S, B, T).bytes;
+}
+
+int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t B, int64_t T,
+                const int64_t* lengths, void* workspace, size_t workspace_bytes, float* loglik, int algo,
+                vit_stream stream) {
+    int rc = check_common(plan, B, T, workspace, workspace_bytes);
+    if (rc != VIT_OK) return rc;
+    if (!logE) return VIT_EINVAL;
+    if (emis_dtype != VIT_F32 && emis_dtype != VIT_F16) return VIT_EINVAL;
+    if (B == 0) return VIT_OK;
+    const bool banded_possible = plan->bp.ok && plan->L.SP <= vit::banded_max_threads(plan->bp.W);
+    if (algo == VIT_ALGO_AUTO) algo = banded_possible ? VIT_ALGO_BANDED : VIT_ALGO_DENSE;
+    if (algo == VIT_ALGO_BANDED && !banded_possible) return VIT_EUNSUPPORTED;
+    if (algo != VIT_ALGO_BANDED && algo != VIT_ALGO_DENSE) return VIT_EINVAL;
+
+    const WsLayout w = ws_layout(plan->S, B, T);
+    uint8_t* ws = static_cast<uint8_t*>(workspace);
+    vit::FwdArgs a{};
+    a.image = plan->dev_image;
+    a.logE = logE;
+    a.lengths = lengths;
+    a.psi = reinterpret_cast<uint16_t*>(ws + w.off_psi);
+    a.last_state = reinterpret_cast<int32_t*>(ws + w.off_last);
+    a.loglik = loglik;
+    a.B = B;
+    a.T = (int)T;
+    a.S = plan->S;
+    a.SP = plan->L.SP;
+    a.S4 = plan->L.S4;
+    a.SPSI = psi_stride(plan->S);
+    a.W = plan->bp.W;
+    a.n_extras = plan->bp.ok ? plan->bp.n_extras : 0;
+    a.n_dense = plan->bp.ok ? plan->bp.n_dense : 0;
+    for (int k = 0; k < vit::kMaxExtras; ++k) a.extras[k] = plan->bp.extras[k];
+    a.c0 = plan->bp.c0;
+    a.off_logpi = plan->L.off_logpi;
+    a.off_A4 = plan->L.off_A4;
+    a.off_lo = plan->L.off_lo;
+    a.off_kind = plan->L.off_kind;
+    a.off_tabA = plan->L.off_tabA;
+    a.off_extraA = plan->L.off_extraA;
+    a.off_denseA = plan->L.off_denseA;
+
+    hipError_t e;
+    if (algo == VIT_ALGO_BANDED) {
+        e = vit::launch_banded(a, emis_dtype == VIT_F16, (hipStream_t)stream);
+    } else {
+        const int ns = B >= 1024 ? 4 : (B >= 512 ? 2 : 1);
+        e = vit::launch_dense(a, ns, emis_dtype == VIT_F16, (hipStream_t)stream);
+    }
+    return e == hipSuccess ? VIT_OK : hip_fail(e);
+}
+
+int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* lengths, void* workspace,
+                  size_t workspace_bytes, int32_t* states, vit_stream stream) {
+    int rc = check_common(plan, B, T, workspace, workspace_bytes);
+    if (rc != VIT_OK) return rc;
+    if (!states) return VIT_EINVAL;
+    if (B == 0) return VIT_OK;
+    const WsLayout w = ws_layout(plan->S, B, T);
+    uint8_t* ws = static_cast<uint8_t*>(workspace);
+    vit::BtArgs b{};
+    b.psi = reinterpret_cast<const uint16_t*>(ws + w.off_psi);
+    b.last_state = reinterpret_cast<const int32_t*>(ws + w.off_last);
+    b.lengths = lengths;
+    b.states = states;
+    b.B = B;
+    b.T = (int)T;
+    b.SPSI = psi_stride(plan->S);
+    hipError_t e = vit::launch_backtrace(b, (hipStream_t)stream);
+    return e == hipSuccess ? VIT_OK : hip_fail(e);
+}
+
+int vit_decode(const vit_plan* plan, const void* logE, int emis_dtype, int64_t B, int64_t T,
+               const int64_t* lengths, void* workspace, size_t workspace_bytes, int32_t* states, float* loglik,
+               int algo, vit_stream stream) {
+    if (!states) return VIT_EINVAL;
+    int rc = vit_forward(plan, logE, emis_dtype, B, T, lengths, workspace, workspace_bytes, loglik, algo, stream);
+    if (rc != VIT_OK) return rc;
+    return vit_backtrace(plan, B, T, lengths, workspace, workspace_bytes, states, stream);
+}
+
+int vit_voicing_map(const int32_t* states, int64_t n, int32_t n_bins, uint8_t* voiced, int32_t* bins,
+                    vit_stream stream) {
+    if (n < 0 || n_bins < 1 || (n > 0 && (!states || !voiced || !bins))) return VIT_EINVAL;
+    hipError_t e = vit::launch_voicing_map(states, n, n_bins, voiced, bins, (hipStream_t)stream);
+    return e == hipSuccess ? VIT_OK : hip_fail(e);
+}
+
+/* not part of the public header: DPP scan self-test used by tests/test_gpu_parity.py */
+int vit_debug_scan(const float* vals, int n_waves, int rev, float* out_v, int32_t* out_i, vit_stream stream) {
+    if (!vals || !out_v || !out_i || n_waves < 1) return VIT_EINVAL;
+    hipError_t e = vit::launch_scan_selftest(vals, n_waves, rev, out_v, out_i, (hipStream_t)stream);
+    return e == hipSuccess ? VIT_OK : hip_fail(e);
+}
+
+}  // extern "C"

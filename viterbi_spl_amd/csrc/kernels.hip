@@ -1,0 +1,497 @@
+// kernels.hip -- gfx950 (MI355X) kernels for the float32 log-domain Viterbi decoder.
+//
+// Semantics (reference: imm/tf_viterbi.py:91-107,
+// tonet/for_paper.py:1855-1868):
+//   delta_0[j]  = fl32(log_pi[j] + logE[0][j])
+//   m_j         = max_i fl32(delta_{t-1}[i] + logA_T[j][i]);  psi_t[j] = LOWEST i attaining it
+//   delta_t[j]  = fl32(m_j + logE[t][j])
+//   s_{T-1}     = lowest argmax_j delta_{T-1}[j];  s_t = psi_{t+1}[s_{t+1}]
+// Only add / compare / select: built with -ffp-contract=off, results are bit-identical to
+// the reference's NumPy float32 loop.
+//
+// Layout: one workgroup per song (dense kernel: NS songs per workgroup sharing every
+// transition tile it streams from L2), one thread per target state, delta resident in
+// LDS for the whole song, emissions read with coalesced loads one frame ahead,
+// back-pointers written as uint16 rows padded to 16 bytes.  No MFMA: the recurrence is
+// max-plus, not an add-contract.
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "kernels.hpp"
+
+namespace vit {
+
+constexpr int kBig = 0x7fffffff;
+
+struct VI {
+    float v;
+    int i;
+};
+
+__device__ __forceinline__ VI vi_identity() { return VI{-INFINITY, kBig}; }
+
+// first-max: `later` (higher source index) replaces `earlier` only if strictly greater
+__device__ __forceinline__ VI op_fwd(VI earlier, VI later) { return later.v > earlier.v ? later : earlier; }
+// pieces visited in DESCENDING source order: the next (lower-index) piece wins ties
+__device__ __forceinline__ VI op_rev(VI acc, VI next) { return next.v >= acc.v ? next : acc; }
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ VI dpp_fetch(VI x) {
+    VI r;
+    r.v = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-INFINITY), __float_as_int(x.v), CTRL,
+                                                     ROW_MASK, 0xf, false));
+    r.i = __builtin_amdgcn_update_dpp(kBig, x.i, CTRL, ROW_MASK, 0xf, false);
+    return r;
+}
+
+// Inclusive wave64 scan over lanes 0..63 with the ordered first-max operator.
+// REV = false: lanes ascend in source index; REV = true: lanes DESCEND in source index.
+// DPP: row_shr:1/2/4/8 inside each row of 16, then row_bcast:15 (rows 1,3), row_bcast:31 (rows 2,3).
+template <bool REV>
+__device__ __forceinline__ VI wave_scan(VI x) {
+#define VIT_SCAN_STEP(CTRL, MASK)                        \
+    {                                                    \
+        VI s = dpp_fetch<CTRL, MASK>(x);                 \
+        x = REV ? op_rev(s, x) : op_fwd(s, x);           \
+    }
+    VIT_SCAN_STEP(0x111, 0xf)
+    VIT_SCAN_STEP(0x112, 0xf)
+    VIT_SCAN_STEP(0x114, 0xf)
+    VIT_SCAN_STEP(0x118, 0xf)
+    VIT_SCAN_STEP(0x142, 0xa)
+    VIT_SCAN_STEP(0x143, 0xc)
+#undef VIT_SCAN_STEP
+    return x;
+}
+
+template <typename ET>
+__device__ __forceinline__ float load_e(const ET* p);
+template <>
+__device__ __forceinline__ float load_e<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float load_e<__half>(const __half* p) { return __half2float(*p); }
+
+__device__ __forceinline__ int song_length(const int64_t* lengths, int song, int T) {
+    if (!lengths) return T;
+    long long v = lengths[song];
+    v = v < 1 ? 1 : v;
+    return v > T ? T : (int)v;
+}
+
+// Workgroup-wide lowest-index argmax of delta (terminal state), result to thread 0.
+__device__ __forceinline__ void terminal_argmax(float dj, int j, int S, VI* tot, int nw, int32_t* last_state,
+                                                float* loglik, int song) {
+    VI x{j < S ? dj : -INFINITY, j < S ? j : kBig};
+    x = wave_scan<false>(x);
+    if ((j & 63) == 63) tot[j >> 6] = x;
+    __syncthreads();
+    if (j == 0) {
+        VI acc = vi_identity();
+        for (int b = 0; b < nw; ++b) acc = op_fwd(acc, tot[b]);
+        if (acc.i == kBig) acc.i = 0;
+        last_state[song] = acc.i;
+        if (loglik) loglik[song] = acc.v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Dense forward kernel: NS songs per workgroup; every thread owns one target state and
+// walks all S sources four at a time.  A4[q][j][0..3] = logA_T[j][4q..4q+3] is a coalesced
+// 16-byte load per lane (L2 resident, 4*S*S bytes), reused for the NS songs; the delta
+// vectors are read from LDS as wave-uniform (broadcast) 16-byte reads.
+// ---------------------------------------------------------------------------------------
+template <int NS, typename ET>
+__global__ void __launch_bounds__(dense_max_threads(NS)) dense_forward_kernel(FwdArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int S = a.S, SP = a.SP, S4 = a.S4, T = a.T;
+    const int SD = S4 * 4;                       // delta row length in LDS (multiple of 4)
+    float* dl = reinterpret_cast<float*>(smem);  // [2][NS][SD]
+    VI* tot = reinterpret_cast<VI*>(dl + 2 * NS * SD);
+
+    const int j = threadIdx.x;
+    const int nw = blockDim.x >> 6;
+    const int song0 = blockIdx.x * NS;
+    const float4* __restrict__ A4 = reinterpret_cast<const float4*>(a.image + a.off_A4);
+    const float* __restrict__ log_pi = reinterpret_cast<const float*>(a.image + a.off_logpi);
+    const ET* __restrict__ E = reinterpret_cast<const ET*>(a.logE);
+
+    int Tb[NS];
+    bool live[NS];
+    int Tmax = 1;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        live[s] = song0 + s < a.B;
+        Tb[s] = live[s] ? song_length(a.lengths, song0 + s, T) : 1;
+        Tmax = Tb[s] > Tmax ? Tb[s] : Tmax;
+    }
+
+    float enext[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const size_t base = (size_t)(song0 + s) * T * S;
+        float d = -INFINITY;
+        if (live[s] && j < S) d = log_pi[j] + load_e<ET>(E + base + j);
+        if (j < SD) { dl[(0 * NS + s) * SD + j] = d; dl[(1 * NS + s) * SD + j] = -INFINITY; }
+        enext[s] = (live[s] && j < S && Tb[s] > 1) ? load_e<ET>(E + base + S + j) : 0.f;
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int t = 1; t < Tmax; ++t) {
+        float ecur[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            ecur[s] = enext[s];
+            if (live[s] && j < S && t + 1 < Tb[s])
+                enext[s] = load_e<ET>(E + ((size_t)(song0 + s) * T + t + 1) * S + j);
+        }
+        float best[NS];
+        int arg[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { best[s] = -INFINITY; arg[s] = kBig; }
+        const float* dcur = dl + cur * NS * SD;
+#pragma unroll 4
+        for (int q = 0; q < S4; ++q) {
+            const float4 av = A4[(size_t)q * SP + j];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const float4 dv = *reinterpret_cast<const float4*>(dcur + s * SD + 4 * q);
+                float v;
+                v = dv.x + av.x; if (v > best[s]) { best[s] = v; arg[s] = 4 * q; }
+                v = dv.y + av.y; if (v > best[s]) { best[s] = v; arg[s] = 4 * q + 1; }
+                v = dv.z + av.z; if (v > best[s]) { best[s] = v; arg[s] = 4 * q + 2; }
+                v = dv.w + av.w; if (v > best[s]) { best[s] = v; arg[s] = 4 * q + 3; }
+            }
+        }
+        float* dnxt = dl + (cur ^ 1) * NS * SD;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (j < S) {
+                if (live[s] && t < Tb[s]) {
+                    const int ai = arg[s] == kBig ? 0 : arg[s];
+                    dnxt[s * SD + j] = best[s] + ecur[s];
+                    a.psi[((size_t)(song0 + s) * T + t) * a.SPSI + j] = (uint16_t)ai;
+                } else {
+                    dnxt[s * SD + j] = dcur[s * SD + j];
+                }
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (live[s]) {
+            const float dj = j < S ? dl[(cur * NS + s) * SD + j] : -INFINITY;
+            terminal_argmax(dj, j, S, tot, nw, a.last_state, a.loglik, song0 + s);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Banded forward kernel: one song per workgroup, one thread per target.
+// Per frame, for a banded target j (window [lo_j, lo_j+W), shared constant c0, extra
+// columns X) the candidates, merged in increasing source order with strict '>':
+//   prefix  first-max_{i < lo_j, i not in X}  fl(delta_i + c0)     (prefix scan, evaluated at lo_j-1)
+//   window  fl(delta_i + logA_T[j][i]),  i in [lo_j, lo_j+W)       (W register-resident entries)
+//   suffix  first-max_{i >= lo_j+W, i not in X} fl(delta_i + c0)   (suffix scan, evaluated at lo_j+W)
+//   extras  fl(delta_x + logA_T[j][x]), x in X                     (lexicographic merge)
+// Dense rows (e.g. the "unvoiced" target) are reduced over all sources by the whole workgroup.
+// Two workgroup barriers per frame; delta, the scan arrays and wave totals live in LDS.
+// ---------------------------------------------------------------------------------------
+template <int W, typename ET>
+__global__ void __launch_bounds__(banded_max_threads(W)) banded_forward_kernel(FwdArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int S = a.S, SP = a.SP, T = a.T;
+    const int NP = blockDim.x;  // == SP
+    const int nw = NP >> 6;
+    float* dl = reinterpret_cast<float*>(smem);       // [NP]
+    VI* pw = reinterpret_cast<VI*>(dl + NP);          // [NP] wave-local inclusive prefix scan
+    VI* sw = pw + NP;                                 // [NP] wave-local inclusive suffix scan
+    VI* ptot = sw + NP;                               // [16]
+    VI* stot = ptot + 16;                             // [16]
+    VI* dtot = stot + 16;                             // [kMaxDense][16]
+
+    const int j = threadIdx.x;
+    const int lane = j & 63, wv = j >> 6;
+    const int jr = NP - 1 - j;  // source handled by this thread in the reversed scan
+    const int song = blockIdx.x;
+    const int Tb = song_length(a.lengths, song, T);
+    const ET* __restrict__ E = reinterpret_cast<const ET*>(a.logE) + (size_t)song * T * S;
+    uint16_t* __restrict__ psi = a.psi + (size_t)song * T * a.SPSI;
+    const float c0 = a.c0;
+    const int nx = a.n_extras, nd = a.n_dense;
+
+    const int lo = reinterpret_cast<const int32_t*>(a.image + a.off_lo)[j];
+    const int kind = reinterpret_cast<const int32_t*>(a.image + a.off_kind)[j];
+    const float* __restrict__ tab = reinterpret_cast<const float*>(a.image + a.off_tabA);
+    const float* __restrict__ xaT = reinterpret_cast<const float*>(a.image + a.off_extraA);
+    const float* __restrict__ daT = reinterpret_cast<const float*>(a.image + a.off_denseA);
+
+    float aw[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) aw[w] = tab[(size_t)w * SP + j];
+    float xa[kMaxExtras], da[kMaxDenseRows];
+    int xcol[kMaxExtras];
+    bool masked = j >= S, masked_r = jr >= S;
+#pragma unroll
+    for (int k = 0; k < kMaxExtras; ++k) {
+        xa[k] = xaT[(size_t)k * SP + j];
+        xcol[k] = a.extras[k];
+        if (k < nx) { masked |= (j == xcol[k]); masked_r |= (jr == xcol[k]); }
+    }
+#pragma unroll
+    for (int d = 0; d < kMaxDenseRows; ++d) da[d] = daT[(size_t)d * SP + j];
+
+    {
+        float d = -INFINITY;
+        if (j < S) d = reinterpret_cast<const float*>(a.image + a.off_logpi)[j] + load_e<ET>(E + j);
+        dl[j] = d;
+    }
+    float enext = (j < S && Tb > 1) ? load_e<ET>(E + S + j) : 0.f;
+    __syncthreads();
+
+    for (int t = 1; t < Tb; ++t) {
+        const float ecur = enext;
+        if (j < S && t + 1 < Tb) enext = load_e<ET>(E + (size_t)(t + 1) * S + j);
+
+        // ---- phase 1: everything that reads delta_{t-1}
+        const float dj = dl[j];
+        const float djr = dl[jr];
+        {
+            VI x{masked ? -INFINITY : dj + c0, masked ? kBig : j};
+            x = wave_scan<false>(x);
+            pw[j] = x;
+            if (lane == 63) ptot[wv] = x;
+            VI y{masked_r ? -INFINITY : djr + c0, masked_r ? kBig : jr};
+            y = wave_scan<true>(y);
+            sw[jr] = y;
+            if (lane == 63) stot[wv] = y;
+        }
+#pragma unroll
+        for (int d = 0; d < kMaxDenseRows; ++d) {
+            if (d < nd) {
+                VI z{dj + da[d], j < S ? j : kBig};
+                z = wave_scan<false>(z);
+                if (lane == 63) dtot[d * 16 + wv] = z;
+            }
+        }
+        float xv[kMaxExtras];
+#pragma unroll
+        for (int k = 0; k < kMaxExtras; ++k) xv[k] = (k < nx) ? dl[xcol[k]] + xa[k] : -INFINITY;
+
+        float best = -INFINITY;
+        int arg = kBig;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const float v = dl[lo + w] + aw[w];
+            if (v > best) { best = v; arg = w; }
+        }
+        __syncthreads();
+
+        // ---- phase 2: merge, write delta_t and the back-pointer
+        VI acc = vi_identity();
+        if (kind == -1) {
+            if (lo > 0) {
+                const int q = lo - 1, pb = q >> 6;
+                for (int b = 0; b < nw; ++b) if (b < pb) acc = op_fwd(acc, ptot[b]);
+                acc = op_fwd(acc, pw[q]);
+            }
+            acc = op_fwd(acc, VI{best, arg == kBig ? kBig : lo + arg});
+            const int qs = lo + W;
+            if (qs < S) {
+                const int rb = (NP - 1 - qs) >> 6;
+                VI sacc = vi_identity();
+                for (int b = 0; b < nw; ++b) if (b < rb) sacc = op_rev(sacc, stot[b]);
+                sacc = op_rev(sacc, sw[qs]);
+                acc = op_fwd(acc, sacc);
+            }
+#pragma unroll
+            for (int k = 0; k < kMaxExtras; ++k)
+                if (k < nx && (xv[k] > acc.v || (xv[k] == acc.v && xcol[k] < acc.i))) acc = VI{xv[k], xcol[k]};
+        } else if (kind >= 0) {
+            for (int b = 0; b < nw; ++b) acc = op_fwd(acc, dtot[kind * 16 + b]);
+        }
+        if (j < S) {
+            if (acc.i == kBig) acc.i = 0;
+            dl[j] = acc.v + ecur;
+            psi[(size_t)t * a.SPSI + j] = (uint16_t)acc.i;
+        }
+        __syncthreads();
+    }
+
+    terminal_argmax(dl[j], j, S, ptot, nw, a.last_state, a.loglik, song);
+}
+
+// ---------------------------------------------------------------------------------------
+// Back-trace: one workgroup per song.  Tiles of K consecutive back-pointer rows are staged
+// through LDS with coalesced 16-byte loads (the next tile is fetched into registers while
+// lane 0 chases the current one), the chase itself runs on LDS latency, and the decoded
+// states of a tile are written back coalesced.
+// ---------------------------------------------------------------------------------------
+constexpr int kBtThreads = 256;
+constexpr int kBtMaxVec = 12;  // 16-byte vectors per thread per tile -> tile <= 48 KiB
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void bt_fetch(u32x4 (&stage)[kBtMaxVec], const u32x4* __restrict__ psi, int top, int K,
+                                         int rowv, int tid) {
+    const int first = top - K + 1 > 1 ? top - K + 1 : 1;  // first row of the tile
+    const int nvec = (top - first + 1) * rowv;
+#pragma unroll
+    for (int v = 0; v < kBtMaxVec; ++v) {
+        const int idx = tid + v * kBtThreads;
+        stage[v] = psi[(size_t)first * rowv + (idx < nvec ? idx : nvec - 1)];  // clamped: always in the tile
+    }
+}
+
+__global__ void __launch_bounds__(kBtThreads) backtrace_kernel(BtArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int K = a.K;
+    const int rowv = a.SPSI / 8;                       // u32x4 per row
+    u32x4* tile = reinterpret_cast<u32x4*>(smem);      // [kBtMaxVec*kBtThreads] (K*rowv of it used)
+    int32_t* out = reinterpret_cast<int32_t*>(tile + kBtMaxVec * kBtThreads);  // [K]
+    int32_t& s_cur = out[K];                                             // chase cursor (lane 0 only)
+
+    const int song = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int T = a.T;
+    const int Tb = song_length(a.lengths, song, T);
+    const u32x4* __restrict__ psi = reinterpret_cast<const u32x4*>(a.psi + (size_t)song * T * a.SPSI);
+    int32_t* __restrict__ states = a.states + (size_t)song * T;
+
+    for (int t = Tb + tid; t < T; t += kBtThreads) states[t] = -1;
+    if (tid == 0) {
+        s_cur = a.last_state[song];
+        states[Tb - 1] = s_cur;
+    }
+
+    // rows t in [1, Tb-1] are consumed from the top; tile covers rows (hi-K, hi]
+    u32x4 stage[kBtMaxVec];
+    int hi = Tb - 1;
+    if (hi >= 1) bt_fetch(stage, psi, hi, K, rowv, tid);
+    while (hi >= 1) {
+        const int first = hi - K + 1 > 1 ? hi - K + 1 : 1;
+        const int rows = hi - first + 1;
+        const int nvec = rows * rowv;
+        __syncthreads();  // previous tile fully consumed
+#pragma unroll
+        for (int v = 0; v < kBtMaxVec; ++v) tile[tid + v * kBtThreads] = stage[v];  // slots >= nvec hold clamped copies
+        __syncthreads();
+        const int next_hi = first - 1;
+        if (next_hi >= 1) bt_fetch(stage, psi, next_hi, K, rowv, tid);
+        if (tid == 0) {
+            const uint16_t* rowsp = reinterpret_cast<const uint16_t*>(tile);
+            int cur = s_cur;
+            for (int r = rows - 1; r >= 0; --r) {
+                cur = rowsp[(size_t)r * a.SPSI + cur];
+                out[r] = cur;                 // state at frame first + r - 1
+            }
+            s_cur = cur;
+        }
+        __syncthreads();
+        for (int r = tid; r < rows; r += kBtThreads) states[first + r - 1] = out[r];
+        hi = next_hi;
+    }
+}
+
+// voiced = state < n_bins; bins = min(state, n_bins-1)  (tonet/for_paper.py:1828-1829)
+__global__ void voicing_map_kernel(const int32_t* __restrict__ states, int64_t n, int32_t n_bins,
+                                   uint8_t* __restrict__ voiced, int32_t* __restrict__ bins) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t s = states[i];
+        voiced[i] = (s >= 0 && s < n_bins) ? 1 : 0;
+        bins[i] = s < 0 ? -1 : (s < n_bins - 1 ? s : n_bins - 1);
+    }
+}
+
+// DPP scan self-test: out[lane] = inclusive first-max scan of (vals[lane], lane) per 64 lanes.
+__global__ void scan_selftest_kernel(const float* __restrict__ vals, int rev, float* __restrict__ out_v,
+                                     int32_t* __restrict__ out_i) {
+    const int j = threadIdx.x + blockIdx.x * blockDim.x;
+    VI x{vals[j], (int)threadIdx.x};
+    x = rev ? wave_scan<true>(x) : wave_scan<false>(x);
+    out_v[j] = x.v;
+    out_i[j] = x.i;
+}
+
+// ---------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------
+template <int NS, typename ET>
+static hipError_t launch_dense_t(const FwdArgs& a, hipStream_t st) {
+    const int SD = a.S4 * 4;
+    const size_t lds = sizeof(float) * 2 * NS * SD + sizeof(VI) * 16;
+    const int grid = (int)((a.B + NS - 1) / NS);
+    hipLaunchKernelGGL((dense_forward_kernel<NS, ET>), dim3(grid), dim3(a.SP), lds, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_dense(const FwdArgs& a, int ns, bool f16, hipStream_t st) {
+    while (ns > 1 && a.SP > dense_max_threads(ns)) ns >>= 1;
+    if (f16) {
+        if (ns >= 4) return launch_dense_t<4, __half>(a, st);
+        if (ns >= 2) return launch_dense_t<2, __half>(a, st);
+        return launch_dense_t<1, __half>(a, st);
+    }
+    if (ns >= 4) return launch_dense_t<4, float>(a, st);
+    if (ns >= 2) return launch_dense_t<2, float>(a, st);
+    return launch_dense_t<1, float>(a, st);
+}
+
+template <int W, typename ET>
+static hipError_t launch_banded_t(const FwdArgs& a, hipStream_t st) {
+    if (a.SP > banded_max_threads(W)) return hipErrorInvalidConfiguration;
+    const size_t lds = sizeof(float) * a.SP + sizeof(VI) * (2 * a.SP + 32 + 16 * kMaxDenseRows);
+    hipLaunchKernelGGL((banded_forward_kernel<W, ET>), dim3((int)a.B), dim3(a.SP), lds, st, a);
+    return hipGetLastError();
+}
+
+template <typename ET>
+static hipError_t launch_banded_e(const FwdArgs& a, hipStream_t st) {
+    switch (a.W) {
+        case 16: return launch_banded_t<16, ET>(a, st);
+        case 28: return launch_banded_t<28, ET>(a, st);
+        case 32: return launch_banded_t<32, ET>(a, st);
+        case 64: return launch_banded_t<64, ET>(a, st);
+        case 96: return launch_banded_t<96, ET>(a, st);
+        case 128: return launch_banded_t<128, ET>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_banded(const FwdArgs& a, bool f16, hipStream_t st) {
+    return f16 ? launch_banded_e<__half>(a, st) : launch_banded_e<float>(a, st);
+}
+
+int backtrace_tile_rows(int SPSI) {
+    int k = (kBtMaxVec * kBtThreads * 16) / (SPSI * 2);
+    return k > 128 ? 128 : (k < 1 ? 1 : k);
+}
+
+hipError_t launch_backtrace(BtArgs a, hipStream_t st) {
+    a.K = backtrace_tile_rows(a.SPSI);
+    const size_t lds = (size_t)kBtMaxVec * kBtThreads * 16 + sizeof(int32_t) * (a.K + 1);
+    hipLaunchKernelGGL(backtrace_kernel, dim3((int)a.B), dim3(kBtThreads), lds, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_voicing_map(const int32_t* states, int64_t n, int32_t n_bins, uint8_t* voiced, int32_t* bins,
+                              hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(voicing_map_kernel, dim3((int)blocks), dim3(256), 0, st, states, n, n_bins, voiced, bins);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_selftest(const float* vals, int n_waves, int rev, float* out_v, int32_t* out_i,
+                                hipStream_t st) {
+    hipLaunchKernelGGL(scan_selftest_kernel, dim3(n_waves), dim3(64), 0, st, vals, rev, out_v, out_i);
+    return hipGetLastError();
+}
+
+}  // namespace vit

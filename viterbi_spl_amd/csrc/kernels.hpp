@@ -1,0 +1,50 @@
+// kernels.hpp -- launch interface between the C ABI (capi.hip) and kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "plan.hpp"
+
+namespace vit {
+
+// threads per workgroup the banded kernel may be launched with for window width W
+// (bounds the VGPR budget: W register-resident transition entries per thread)
+constexpr int banded_max_threads(int W) { return W <= 32 ? 1024 : (W <= 64 ? 512 : 256); }
+// the dense kernel keeps NS running (best, arg) pairs per thread
+constexpr int dense_max_threads(int NS) { return NS <= 2 ? 1024 : 512; }
+
+struct FwdArgs {
+    const uint8_t* image;   // device plan image
+    const void* logE;       // [B,T,S] f32 or f16
+    const int64_t* lengths; // [B] or null
+    uint16_t* psi;          // [B,T,SPSI]
+    int32_t* last_state;    // [B]
+    float* loglik;          // [B] or null
+    int64_t B;
+    int T, S, SP, S4, SPSI, W;
+    int n_extras, n_dense;
+    int extras[kMaxExtras];
+    float c0;
+    size_t off_logpi, off_A4, off_lo, off_kind, off_tabA, off_extraA, off_denseA;
+};
+
+struct BtArgs {
+    const uint16_t* psi;
+    const int32_t* last_state;
+    const int64_t* lengths;
+    int32_t* states;        // [B,T]
+    int64_t B;
+    int T, SPSI, K;
+};
+
+hipError_t launch_dense(const FwdArgs& a, int songs_per_group, bool f16, hipStream_t st);
+hipError_t launch_banded(const FwdArgs& a, bool f16, hipStream_t st);
+hipError_t launch_backtrace(BtArgs a, hipStream_t st);
+hipError_t launch_voicing_map(const int32_t* states, int64_t n, int32_t n_bins, uint8_t* voiced, int32_t* bins,
+                              hipStream_t st);
+hipError_t launch_scan_selftest(const float* vals, int n_waves, int rev, float* out_v, int32_t* out_i,
+                                hipStream_t st);
+int backtrace_tile_rows(int SPSI);
+
+}  // namespace vit

@@ -1,0 +1,175 @@
+// plan.cpp -- see plan.hpp.  Host-only C++17.
+#include "plan.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <map>
+
+namespace vit {
+
+static inline uint32_t f2u(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return u;
+}
+
+static inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+static const int kWidths[] = {16, 28, 32, 64, 96, 128};
+
+BandedPlan analyze_banded(const float* A, int S) {
+    BandedPlan bp;
+    bp.S = S;
+    bp.SP = (S + 63) / 64 * 64;
+    bp.lo.assign(bp.SP, 0);
+    bp.kind.assign(bp.SP, -2);
+    if (S < 32) return bp;  // nothing to gain; the dense kernel handles it
+
+    // 1. modal bit pattern of every row
+    std::vector<uint32_t> row_mode(S);
+    std::vector<uint32_t> tmp(S);
+    for (int j = 0; j < S; ++j) {
+        for (int i = 0; i < S; ++i) tmp[i] = f2u(A[(size_t)j * S + i]);
+        std::sort(tmp.begin(), tmp.end());
+        int best_run = 0, run = 0;
+        uint32_t best_val = tmp[0];
+        for (int i = 0; i < S; ++i) {
+            run = (i > 0 && tmp[i] == tmp[i - 1]) ? run + 1 : 1;
+            if (run > best_run) { best_run = run; best_val = tmp[i]; }
+        }
+        row_mode[j] = best_val;
+    }
+    // 2. the constant shared by most rows
+    std::map<uint32_t, int> votes;
+    for (int j = 0; j < S; ++j) votes[row_mode[j]]++;
+    uint32_t c0 = row_mode[0];
+    int c0_rows = 0;
+    for (auto& kv : votes) if (kv.second > c0_rows) { c0_rows = kv.second; c0 = kv.first; }
+    if (c0_rows < S / 2) return bp;
+    float c0f;
+    std::memcpy(&c0f, &c0, 4);
+    if (std::isnan(c0f)) return bp;
+    bp.c0 = c0f;
+
+    // 3. extra columns: exceptions shared by more than a quarter of the c0 rows
+    std::vector<int> col_exc(S, 0);
+    for (int j = 0; j < S; ++j) {
+        if (row_mode[j] != c0) continue;
+        for (int i = 0; i < S; ++i) col_exc[i] += (f2u(A[(size_t)j * S + i]) != c0);
+    }
+    std::vector<int> cand;
+    for (int i = 0; i < S; ++i) if (col_exc[i] > c0_rows / 4) cand.push_back(i);
+    if ((int)cand.size() > kMaxExtras) return bp;
+    bp.n_extras = (int)cand.size();
+    for (int k = 0; k < bp.n_extras; ++k) bp.extras[k] = cand[k];
+    auto is_extra = [&](int i) {
+        for (int k = 0; k < bp.n_extras; ++k) if (bp.extras[k] == i) return true;
+        return false;
+    };
+
+    // 4. per-row exception windows
+    std::vector<int> lo(S, 0), hi(S, 0);
+    std::vector<int> dense;
+    int max_window = 1;
+    for (int j = 0; j < S; ++j) {
+        if (row_mode[j] != c0) { dense.push_back(j); continue; }
+        int l = S, h = -1;
+        for (int i = 0; i < S; ++i) {
+            if (is_extra(i) || f2u(A[(size_t)j * S + i]) == c0) continue;
+            l = std::min(l, i);
+            h = std::max(h, i);
+        }
+        if (h < l) { l = h = std::min(j, S - 1); }
+        if (h - l + 1 > kMaxWindow) { dense.push_back(j); continue; }
+        lo[j] = l;
+        hi[j] = h;
+        max_window = std::max(max_window, h - l + 1);
+    }
+    if ((int)dense.size() > kMaxDenseRows) return bp;
+    bp.n_dense = (int)dense.size();
+    for (int d = 0; d < bp.n_dense; ++d) bp.dense_rows[d] = dense[d];
+    bp.max_window = max_window;
+
+    // 5. evaluated window width
+    int W = 0;
+    for (int w : kWidths) if (w >= max_window) { W = w; break; }
+    if (W == 0 || W > S || 2 * W > S) return bp;  // too wide to beat the dense kernel
+    bp.W = W;
+
+    for (int j = 0; j < S; ++j) {
+        bp.kind[j] = -1;
+        bp.lo[j] = std::max(0, std::min(lo[j], S - W));
+    }
+    for (int d = 0; d < bp.n_dense; ++d) { bp.kind[dense[d]] = d; bp.lo[dense[d]] = 0; }
+
+    // 6. proof obligation, re-checked from the bits: outside [lo, lo+W) and the
+    //    extra columns every entry of a banded row equals c0.
+    for (int j = 0; j < S; ++j) {
+        if (bp.kind[j] != -1) continue;
+        for (int i = 0; i < S; ++i) {
+            const bool inside = i >= bp.lo[j] && i < bp.lo[j] + W;
+            if (!inside && !is_extra(i) && f2u(A[(size_t)j * S + i]) != c0) return bp;
+        }
+    }
+    bp.ok = true;
+    return bp;
+}
+
+ImageLayout make_layout(int S, const BandedPlan& bp) {
+    ImageLayout L;
+    L.S = S;
+    L.SP = (S + 63) / 64 * 64;
+    L.S4 = (S + 3) / 4;
+    L.W = bp.ok ? bp.W : 0;
+    L.n_extras = bp.ok ? bp.n_extras : 0;
+    L.n_dense = bp.ok ? bp.n_dense : 0;
+    size_t off = 0;
+    L.off_logpi = off;  off = align256(off + sizeof(float) * L.SP);
+    L.off_A4 = off;     off = align256(off + sizeof(float) * 4 * (size_t)L.S4 * L.SP);
+    L.off_lo = off;     off = align256(off + sizeof(int32_t) * L.SP);
+    L.off_kind = off;   off = align256(off + sizeof(int32_t) * L.SP);
+    L.off_tabA = off;   off = align256(off + sizeof(float) * (size_t)std::max(L.W, 1) * L.SP);
+    L.off_extraA = off; off = align256(off + sizeof(float) * kMaxExtras * L.SP);
+    L.off_denseA = off; off = align256(off + sizeof(float) * kMaxDenseRows * L.SP);
+    L.bytes = off;
+    return L;
+}
+
+void fill_image(const float* A, const float* log_pi, const BandedPlan& bp, const ImageLayout& L,
+                uint8_t* image) {
+    const float ninf = -std::numeric_limits<float>::infinity();
+    const int S = L.S, SP = L.SP;
+    std::memset(image, 0, L.bytes);
+    float* pi = reinterpret_cast<float*>(image + L.off_logpi);
+    for (int j = 0; j < SP; ++j) pi[j] = j < S ? log_pi[j] : ninf;
+
+    float* A4 = reinterpret_cast<float*>(image + L.off_A4);
+    for (int q = 0; q < L.S4; ++q)
+        for (int j = 0; j < SP; ++j)
+            for (int r = 0; r < 4; ++r) {
+                const int i = 4 * q + r;
+                A4[((size_t)q * SP + j) * 4 + r] = (j < S && i < S) ? A[(size_t)j * S + i] : ninf;
+            }
+
+    int32_t* lo = reinterpret_cast<int32_t*>(image + L.off_lo);
+    int32_t* kind = reinterpret_cast<int32_t*>(image + L.off_kind);
+    float* tab = reinterpret_cast<float*>(image + L.off_tabA);
+    float* xa = reinterpret_cast<float*>(image + L.off_extraA);
+    float* da = reinterpret_cast<float*>(image + L.off_denseA);
+    for (int j = 0; j < SP; ++j) { lo[j] = 0; kind[j] = -2; }
+    for (int k = 0; k < kMaxExtras; ++k) for (int j = 0; j < SP; ++j) xa[(size_t)k * SP + j] = ninf;
+    for (int d = 0; d < kMaxDenseRows; ++d) for (int j = 0; j < SP; ++j) da[(size_t)d * SP + j] = ninf;
+    if (!bp.ok) return;
+    for (int j = 0; j < S; ++j) { lo[j] = bp.lo[j]; kind[j] = bp.kind[j]; }
+    for (int w = 0; w < L.W; ++w)
+        for (int j = 0; j < SP; ++j)
+            tab[(size_t)w * SP + j] = j < S ? A[(size_t)j * S + bp.lo[j] + w] : ninf;
+    for (int k = 0; k < bp.n_extras; ++k)
+        for (int j = 0; j < S; ++j) xa[(size_t)k * SP + j] = A[(size_t)j * S + bp.extras[k]];
+    for (int d = 0; d < bp.n_dense; ++d)
+        for (int i = 0; i < S; ++i) da[(size_t)d * SP + i] = A[(size_t)bp.dense_rows[d] * S + i];
+}
+
+}  // namespace vit

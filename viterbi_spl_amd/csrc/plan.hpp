@@ -1,0 +1,65 @@
+// plan.hpp -- host-side analysis of a log-domain transition matrix.
+//
+// Pure C++ (no HIP): compiled into libviterbi_hip.so by hipcc and into
+// libviterbi_plan_host.so by g++ so that the analysis and the exactness of the
+// banded decomposition can be tested on a machine without a GPU.
+//
+// The decomposition: the production matrices built by the
+// reference's */viterbi_transition_post_processing.py are
+//   band(+/- d_max) + one dense row + one dense column, every other entry the
+//   single constant c = log(0 + tiny).
+// For a target row j whose entries outside a window [lo_j, hi_j] and outside a
+// few shared "extra" columns all equal the same constant c, the candidates
+// fl(delta_i + c) outside the window are the same numbers for every such row, so
+// their first-max is a prefix/suffix first-max scan evaluated at the window
+// edges.  Every value compared is one the dense recursion also computes, and
+// candidates are merged in increasing source order with a strict '>', so the
+// result is bit-identical to the dense recursion.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace vit {
+
+constexpr int kMaxExtras = 4;
+constexpr int kMaxDenseRows = 4;
+constexpr int kMaxWindow = 128;
+
+struct BandedPlan {
+    bool ok = false;          // the decomposition was proven for this matrix
+    int S = 0;
+    int SP = 0;               // S rounded up to a multiple of 64 (threads per workgroup)
+    float c0 = 0.f;           // the shared row constant (bit pattern compared exactly)
+    int n_extras = 0;
+    int extras[kMaxExtras] = {0, 0, 0, 0};
+    int n_dense = 0;
+    int dense_rows[kMaxDenseRows] = {0, 0, 0, 0};
+    int max_window = 0;       // widest proven exception window among banded rows
+    int W = 0;                // window width the kernel evaluates (16/32/64/128)
+    std::vector<int32_t> lo;  // [SP] first source of the evaluated window (lo + W <= S)
+    std::vector<int32_t> kind;// [SP] -1 banded row, d >= 0 dense row d, -2 padding
+};
+
+// Analyse logA_T ([S,S] row-major, row j = into target j).
+BandedPlan analyze_banded(const float* logA_T, int S);
+
+// Byte layout of the device image (all offsets in bytes from the image base,
+// every section 256-byte aligned).
+struct ImageLayout {
+    int S = 0, SP = 0, S4 = 0, W = 0, n_extras = 0, n_dense = 0;
+    size_t off_logpi = 0;    // float [SP]          (-inf padded)
+    size_t off_A4 = 0;       // float [S4][SP][4]   A4[q][j][r] = logA_T[j][4q+r] (-inf padded)
+    size_t off_lo = 0;       // int32 [SP]
+    size_t off_kind = 0;     // int32 [SP]
+    size_t off_tabA = 0;     // float [W][SP]       tabA[w][j] = logA_T[j][lo_j + w]
+    size_t off_extraA = 0;   // float [4][SP]       extraA[k][j] = logA_T[j][extras[k]]
+    size_t off_denseA = 0;   // float [4][SP]       denseA[d][i] = logA_T[dense_rows[d]][i]
+    size_t bytes = 0;
+};
+
+ImageLayout make_layout(int S, const BandedPlan& bp);
+void fill_image(const float* logA_T, const float* log_pi, const BandedPlan& bp,
+                const ImageLayout& L, uint8_t* image);
+
+}  // namespace vit

@@ -1,0 +1,201 @@
+"""Host side of the MI355X Viterbi decoder: torch tensors in, ctypes C ABI underneath.
+
+``decode(emission_logits, transition_matrix, init_probs)`` is the call surface named by
+BASELINE.json; it follows the reference's log-domain core
+``viterbi_librosa_fn(*, log_transition_matrix_T, log_prob_init, log_probs_st)``
+(imm/tf_viterbi.py:75-109 in the reference repo) with these conventions:
+
+* ``transition_matrix`` -- LOG-domain, transposed: ``[S, S]`` float32 with row ``j`` = log-probabilities
+  INTO target ``j`` (what the reference calls ``log_transition_matrix_T`` / ``B``,
+  tonet/for_paper.py:1798-1815);
+* ``init_probs``        -- LOG-domain ``[S]`` float32 (``log_prob_init``);
+* ``emission_logits``   -- LOG-domain ``[T, S]`` or ``[B, T, S]`` float32/float16, C-contiguous, on the GPU
+  (time-major rows, the layout the reference hands its core: dcnet/tf_viterbi_decoding.py:145).
+
+PyTorch is plumbing only here (device memory, streams); all arithmetic happens in
+libviterbi_hip.so.  Nothing in this module falls back to the CPU.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _as_host_f32(x, shape=None) -> np.ndarray:
+    if isinstance(x, torch.Tensor):
+        x = x.detach().cpu().numpy()
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    if shape is not None and a.shape != shape:
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+class ViterbiDecoder:
+    """A transition matrix + prior analysed once and resident on one GPU.
+
+    Mirrors the reference's ``Viterbi.__init__`` (tonet/for_paper.py:1685-1701): parameters are
+    prepared once, then many songs are decoded.
+    """
+
+    def __init__(self, log_transition_matrix_T, log_prob_init, device: Optional[torch.device] = None):
+        lib = _lib.load()
+        A = _as_host_f32(log_transition_matrix_T)
+        if A.ndim != 2 or A.shape[0] != A.shape[1]:
+            raise ValueError("log_transition_matrix_T must be [S, S]")
+        S = A.shape[0]
+        pi = _as_host_f32(log_prob_init, (S,))
+        if np.isnan(A).any() or np.isnan(pi).any():
+            raise ValueError("NaN in HMM parameters")
+        self.S = S
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self.device.type != "cuda":
+            raise ValueError("ViterbiDecoder needs a GPU device (there is no CPU path)")
+        self._plan = ctypes.c_void_p()
+        _lib.check(lib.vit_plan_create(A.ctypes.data, pi.ctypes.data, S, ctypes.byref(self._plan)), "vit_plan_create")
+        info = _lib.PlanInfo()
+        _lib.check(lib.vit_plan_query(self._plan, ctypes.byref(info)), "vit_plan_query")
+        self.info = {
+            "S": int(info.S), "banded_ok": bool(info.banded_ok), "n_extras": int(info.n_extras),
+            "n_dense_rows": int(info.reserved[0]), "max_window": int(info.max_window),
+            "group_window": int(info.group_window), "row_constant": float(info.consts[0]),
+            "extras": [int(info.extras[k]) for k in range(int(info.n_extras))],
+        }
+        nbytes = int(lib.vit_plan_image_bytes(self._plan))
+        with torch.cuda.device(self.device):
+            self._image = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+            self._image_ptr = (self._image.data_ptr() + 255) & ~255
+            stream = torch.cuda.current_stream(self.device)
+            _lib.check(lib.vit_plan_upload(self._plan, self._image_ptr, nbytes, stream.cuda_stream), "vit_plan_upload")
+            stream.synchronize()  # host image is pageable: make the copy visible before anything else
+        self._ws: Optional[torch.Tensor] = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_plan", None) is not None and self._plan.value:
+                _lib.load().vit_plan_destroy(self._plan)
+                self._plan = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ workspace
+    def workspace_bytes(self, B: int, T: int) -> int:
+        return int(_lib.load().vit_workspace_bytes(self._plan, B, T))
+
+    def _workspace(self, B: int, T: int) -> Tuple[int, int]:
+        need = self.workspace_bytes(B, T)
+        if self._ws is None or self._ws.numel() < need + 256:
+            self._ws = None
+            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+        return (self._ws.data_ptr() + 255) & ~255, need
+
+    # ------------------------------------------------------------------ checks
+    def _check_emissions(self, logE: torch.Tensor) -> Tuple[torch.Tensor, bool, int]:
+        if not isinstance(logE, torch.Tensor):
+            raise TypeError("emission_logits must be a torch tensor on the GPU")
+        if logE.device != self.device:
+            raise ValueError(f"emission_logits is on {logE.device}, decoder is on {self.device}")
+        if logE.dtype == torch.float32:
+            dt = _lib.VIT_F32
+        elif logE.dtype == torch.float16:
+            dt = _lib.VIT_F16
+        else:
+            raise TypeError("emission_logits must be float32 or float16")
+        single = logE.dim() == 2
+        if single:
+            logE = logE.unsqueeze(0)
+        if logE.dim() != 3 or logE.shape[2] != self.S or logE.shape[1] < 1:
+            raise ValueError(f"emission_logits must be [B,T,{self.S}] or [T,{self.S}] with T >= 1")
+        if not logE.is_contiguous():
+            raise ValueError("emission_logits must be C-contiguous (the reference requires it too)")
+        return logE, single, dt
+
+    # ------------------------------------------------------------------ decode
+    def decode_into(self, logE: torch.Tensor, states: torch.Tensor, loglik: Optional[torch.Tensor] = None,
+                    lengths: Optional[torch.Tensor] = None, algo: str = "auto", phase: str = "both") -> None:
+        """Enqueue a decode on the current stream.  states: int32 [B,T]; loglik: float32 [B]."""
+        lib = _lib.load()
+        logE, _, dt = self._check_emissions(logE)
+        B, T, _ = logE.shape
+        if states.dtype != torch.int32 or tuple(states.shape) != (B, T) or not states.is_contiguous():
+            raise ValueError("states must be a contiguous int32 [B,T] tensor")
+        if loglik is not None and (loglik.dtype != torch.float32 or tuple(loglik.shape) != (B,)):
+            raise ValueError("loglik must be float32 [B]")
+        if lengths is not None:
+            if lengths.dtype != torch.int64 or tuple(lengths.shape) != (B,) or lengths.device != self.device:
+                raise ValueError("lengths must be an int64 [B] tensor on the decoder's device")
+        ws_ptr, ws_bytes = self._workspace(B, T)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            len_ptr = lengths.data_ptr() if lengths is not None else None
+            ll_ptr = loglik.data_ptr() if loglik is not None else None
+            a = _lib.ALGO[algo]
+            if phase == "both":
+                rc = lib.vit_decode(self._plan, logE.data_ptr(), dt, B, T, len_ptr, ws_ptr, ws_bytes,
+                                    states.data_ptr(), ll_ptr, a, stream)
+            elif phase == "forward":
+                rc = lib.vit_forward(self._plan, logE.data_ptr(), dt, B, T, len_ptr, ws_ptr, ws_bytes, ll_ptr, a, stream)
+            elif phase == "backtrace":
+                rc = lib.vit_backtrace(self._plan, B, T, len_ptr, ws_ptr, ws_bytes, states.data_ptr(), stream)
+            else:
+                raise ValueError(phase)
+        _lib.check(rc, f"vit_{phase if phase != 'both' else 'decode'}")
+
+    def decode(self, emission_logits: torch.Tensor, lengths: Optional[torch.Tensor] = None, algo: str = "auto",
+               out_dtype: torch.dtype = torch.int64) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Returns (states [B,T] or [T] of ``out_dtype`` (reference: int64), loglik float32 [B] or scalar)."""
+        logE, single, _ = self._check_emissions(emission_logits)
+        B, T, _ = logE.shape
+        states = torch.empty((B, T), dtype=torch.int32, device=self.device)
+        loglik = torch.empty((B,), dtype=torch.float32, device=self.device)
+        if B > 0:
+            self.decode_into(logE, states, loglik, lengths, algo)
+        if out_dtype != torch.int32:
+            states = states.to(out_dtype)
+        return (states[0], loglik[0]) if single else (states, loglik)
+
+    def voicing(self, states: torch.Tensor, n_bins: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """voiced = state < n_bins, bins = min(state, n_bins-1) (tonet/for_paper.py:1828-1829)."""
+        n_bins = self.S - 1 if n_bins is None else int(n_bins)
+        st = states.to(torch.int32).contiguous()
+        voiced = torch.empty(st.shape, dtype=torch.uint8, device=st.device)
+        bins = torch.empty(st.shape, dtype=torch.int32, device=st.device)
+        with torch.cuda.device(st.device):
+            rc = _lib.load().vit_voicing_map(st.data_ptr(), st.numel(), n_bins, voiced.data_ptr(), bins.data_ptr(),
+                                             torch.cuda.current_stream(st.device).cuda_stream)
+        _lib.check(rc, "vit_voicing_map")
+        return voiced.bool(), bins
+
+
+_DECODERS: dict = {}
+
+
+def get_decoder(transition_matrix, init_probs, device=None) -> ViterbiDecoder:
+    """Decoder cache keyed by the parameter bits and the device (parameters are prepared once per
+    process in the reference too: tonet/for_paper.py:281-286)."""
+    A = _as_host_f32(transition_matrix)
+    pi = _as_host_f32(init_probs)
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = (hash(A.tobytes()), hash(pi.tobytes()), A.shape, str(dev))
+    dec = _DECODERS.get(key)
+    if dec is None:
+        if len(_DECODERS) >= 8:
+            _DECODERS.pop(next(iter(_DECODERS)))
+        dec = ViterbiDecoder(A, pi, dev)
+        _DECODERS[key] = dec
+    return dec
+
+
+def decode(emission_logits: torch.Tensor, transition_matrix, init_probs, lengths: Optional[torch.Tensor] = None,
+           algo: str = "auto", out_dtype: torch.dtype = torch.int64) -> Tuple[torch.Tensor, torch.Tensor]:
+    """decode(emission_logits, transition_matrix, init_probs) -> (states, loglik).  See module docstring."""
+    if not isinstance(emission_logits, torch.Tensor) or emission_logits.device.type != "cuda":
+        raise ValueError("emission_logits must be a torch tensor on a ROCm GPU (there is no CPU path)")
+    dec = get_decoder(transition_matrix, init_probs, emission_logits.device)
+    return dec.decode(emission_logits, lengths=lengths, algo=algo, out_dtype=out_dtype)

@@ -1,0 +1,169 @@
+"""Signature-compatible adapters for the reference's Viterbi entry points.
+
+Same names, keyword arguments, argument meaning and assertion behaviour as the reference
+functions they replace (paths relative to the reference repo); the forward recursion and the
+back-trace run on the GPU through ``ViterbiDecoder``.  The prob -> log step stays on the host in
+NumPy float32 exactly where the reference does it, because ``np.log`` is the one operation whose
+last bit a GPU cannot be trusted to reproduce.
+
+  family A  viterbi_librosa_c_fn / viterbi_numba_fn(*, transition_matrix, prob_init, probs_st)
+            dcnet/tf_viterbi_decoding.py:119-207, dcnet/main.py:2417-2468 (+10 copies)
+  family D  viterbi_librosa_fn(*, log_transition_matrix_T, log_prob_init, log_probs_st)
+            imm/tf_viterbi.py:75-109
+  AOT core  viterbi_numba_core(B, prob_init, probs)   dcnet/aot_viterbi_core.py:8-54
+  family B  Viterbi.viterbi_librosa_fn(self, probs_st)          tonet/for_paper.py:1833-1870
+  family C  SoftMaxViterbi.viterbi_librosa_fn(self, probs_ts)   tonet/for_paper.py:1999-2037
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .decoder import ViterbiDecoder, get_decoder
+
+_TINY = np.finfo(np.float32).tiny
+
+
+def _run(logA_T: np.ndarray, log_pi: np.ndarray, logE_ts: np.ndarray, decoder: ViterbiDecoder | None = None) -> np.ndarray:
+    dec = decoder if decoder is not None else get_decoder(logA_T, log_pi)
+    e = torch.from_numpy(np.ascontiguousarray(logE_ts, dtype=np.float32)).to(dec.device)
+    states, _ = dec.decode(e, out_dtype=torch.int64)
+    return states.cpu().numpy()
+
+
+# ----------------------------------------------------------------------------- family D
+def viterbi_librosa_fn(*, log_transition_matrix_T, log_prob_init, log_probs_st):
+    """Log-domain core (imm/tf_viterbi.py:75-109): emissions are [S, T]; returns int64[T]."""
+    B = log_transition_matrix_T
+    assert B.flags['C_CONTIGUOUS']
+    assert B.dtype == np.float32
+    S = len(B)
+    assert len(log_prob_init) == S
+    assert log_probs_st.dtype == np.float32
+    assert log_probs_st.shape[0] == S
+    logE = np.require(log_probs_st.T, requirements=['C'])
+    return _run(B, np.asarray(log_prob_init, np.float32), logE)
+
+
+# ----------------------------------------------------------------------------- family A
+def _check_probs(transition_matrix, prob_init, probs_st):
+    S = len(transition_matrix)
+    assert transition_matrix.shape == (S, S)
+    assert probs_st.shape[0] == S and probs_st.ndim == 2
+    assert np.allclose(np.sum(transition_matrix, axis=1), 1.)
+    assert len(prob_init) == S
+    assert np.isclose(np.sum(prob_init), 1.)
+    return S
+
+
+def viterbi_librosa_c_fn(*, transition_matrix, prob_init, probs_st):
+    """Probabilities in, [S, T] emissions (dcnet/tf_viterbi_decoding.py:156-207); int64[T] out."""
+    _check_probs(transition_matrix, prob_init, probs_st)
+    tinyp = np.finfo(probs_st.dtype).tiny
+    logA_T = np.require(np.log(transition_matrix.T + tinyp), np.float32, ['C'])
+    log_pi = np.log(prob_init + tinyp).astype(np.float32)
+    logE = np.require(np.log(probs_st.T + tinyp), np.float32, ['C'])
+    return _run(logA_T, log_pi, logE)
+
+
+def viterbi_numba_fn(*, transition_matrix, prob_init, probs_st):
+    """The marshalling wrapper around the AOT core (dcnet/tf_viterbi_decoding.py:119-153)."""
+    _check_probs(transition_matrix, prob_init, probs_st)
+    B = np.require(transition_matrix.T, requirements=['C']).copy()
+    probs = np.require(probs_st.T, requirements=['C']).copy()
+    return viterbi_numba_core(B, prob_init.copy(), probs)
+
+
+def viterbi_numba_core(B, prob_init, probs):
+    """Stand-in for ``viterbi_numba.core`` ('i8[:](f4[:, ::1], f4[:], f4[:, ::1])',
+    dcnet/aot_viterbi_core.py:8-54).  B is [S,S] "target <- source", probs is [T,S].
+    Like the Numba core it log-transforms its arguments IN PLACE (:23-25)."""
+    assert B.dtype == np.float32 and prob_init.dtype == np.float32 and probs.dtype == np.float32
+    assert B.flags['C_CONTIGUOUS'] and probs.flags['C_CONTIGUOUS']
+    S = B.shape[0]
+    assert prob_init.shape[0] == S and probs.shape[1] == S
+    tinyp = np.float32(1.1754944e-38)
+    B[:] = np.log(B + tinyp)
+    prob_init[:] = np.log(prob_init + tinyp)
+    probs[:] = np.log(probs + tinyp)
+    return _run(B, prob_init, probs)
+
+
+# ----------------------------------------------------------------------------- families B / C
+class _PreparedViterbi:
+    """Parameters logged and transposed once (tonet/for_paper.py:1780-1815)."""
+
+    def __init__(self, transition_matrix, init_probs, num_freq_bins=None, device=None):
+        transition_matrix = np.asarray(transition_matrix)
+        init_probs = np.asarray(init_probs)
+        U = transition_matrix.shape[0] - 1 if num_freq_bins is None else int(num_freq_bins)
+        self.num_freq_bins = U
+        assert transition_matrix.shape == (U + 1, U + 1)
+        assert np.all(np.isclose(np.sum(transition_matrix, axis=1), 1))
+        assert init_probs.shape == (U + 1,)
+        assert np.isclose(np.sum(init_probs), 1)
+        tiny = np.finfo(np.float32).tiny
+        t = np.log(transition_matrix + tiny)
+        assert not np.any(np.isneginf(t))
+        t = np.require(t.T, np.float32, ['C'])
+        t.flags['WRITEABLE'] = False
+        self.log_transition_matrix_T = t
+        p = np.log(init_probs + tiny)
+        assert not np.any(np.isneginf(p))
+        p = np.require(p, np.float32)
+        p.flags['WRITEABLE'] = False
+        self.log_ini_probs = p
+        self._decoder = ViterbiDecoder(t, p, device)
+
+    @classmethod
+    def from_dat_files(cls, transition_file, init_file, **kw):
+        from .datfile import load_np_array_from_file_fn
+        name, A = load_np_array_from_file_fn(transition_file)
+        assert name == 'viterbi_transition_matrix'
+        name, pi = load_np_array_from_file_fn(init_file)
+        assert name == 'viterbi_init_probs'
+        return cls(A, pi, **kw)
+
+    def _post(self, bins):
+        n_bins = self.num_freq_bins
+        voiced = bins < n_bins
+        bins = np.minimum(bins, n_bins - 1)
+        return voiced, bins
+
+
+class Viterbi(_PreparedViterbi):
+    """Family B (tonet/for_paper.py:1683-1870): emissions arrive as F-contiguous [S, T]
+    probabilities and are logged IN PLACE, as in the reference."""
+
+    def viterbi_librosa_fn(self, probs_st):
+        S = self.num_freq_bins + 1
+        assert probs_st.shape[0] == S
+        assert probs_st.dtype == np.float32
+        assert probs_st.flags['F_CONTIGUOUS']
+        np.add(probs_st, _TINY, out=probs_st)
+        np.log(probs_st, out=probs_st)
+        probs = np.require(probs_st.T, np.float32, ['C'])
+        return _run(self.log_transition_matrix_T, self.log_ini_probs, probs, self._decoder)
+
+    def __call__(self, observation_probs_st):
+        """Decode + the (voiced, bins) post-map of Viterbi.__call__ (:1817-1831).  The
+        logits -> observation-probability builder (:1733-1778) is upstream of this path."""
+        return self._post(self.viterbi_librosa_fn(observation_probs_st))
+
+
+class SoftMaxViterbi(_PreparedViterbi):
+    """Family C (tonet/for_paper.py:1873-2037): C-contiguous [T, S] probabilities (values may
+    exceed 1 for scaled likelihoods), logged IN PLACE."""
+
+    def viterbi_librosa_fn(self, probs_ts):
+        S = self.num_freq_bins + 1
+        assert probs_ts.ndim == 2
+        assert probs_ts.shape[1] == S
+        assert probs_ts.dtype == np.float32
+        assert probs_ts.flags['C_CONTIGUOUS']
+        np.add(probs_ts, _TINY, out=probs_ts)
+        np.log(probs_ts, out=probs_ts)
+        return _run(self.log_transition_matrix_T, self.log_ini_probs, probs_ts, self._decoder)
+
+    def __call__(self, observation_probs_ts):
+        return self._post(self.viterbi_librosa_fn(observation_probs_ts))
