@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- Viterbi Mframes/s at S=361, T=30000 on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic songs per GPU:
+forward max-plus recursion + back-trace for [B=128, T=30000, S=361] float32 log-emissions
+already resident in HBM, plus (N > 1) the RCCL gather of the decoded paths on rank 0.
+Per-GPU work is fixed as N grows (weak scaling: 128 songs per GPU = BASELINE configs[2],
+and configs[3] = 1024 songs over 8 GPUs).
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  The CPU baseline leg (rank 0, N == 1 only) runs the oracle --
+the NumPy restatement of the reference's loop, one thread -- on a bounded sample of the same
+songs and doubles as a parity check of the GPU result.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from viterbi_spl_amd import ViterbiDecoder, sharded, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=128, help="songs per GPU")
+    ap.add_argument("--frames", type=int, default=30000)
+    ap.add_argument("--states", type=int, default=361)
+    ap.add_argument("--algo", default="auto", choices=["auto", "dense", "banded"])
+    ap.add_argument("--emissions", default="peaks", choices=["peaks", "dense"])
+    ap.add_argument("--transition", default="tonet", choices=["tonet", "dense"])
+    ap.add_argument("--f16", action="store_true", help="store emissions as float16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def make_params(args):
+    S = args.states
+    if args.transition == "tonet":
+        return synth.log_params(synth.tonet_transition(S - 1, 14), synth.floored_prior(S))
+    return synth.dense_random_log_transition(S, seed=3), synth.dense_random_log_transition(S, seed=4)[0].copy()
+
+
+def cpu_baseline(logA_T, log_pi, E, gpu_states, gpu_loglik, seconds):
+    """Oracle (NumPy restatement of imm/tf_viterbi.py:91-107, one thread) on the first songs of the
+    batch until ~`seconds` of CPU time; also the C restatement on all cores.  Checks parity."""
+    from oracle import viterbi_oracle as vo
+    T = E.shape[1]
+    done, frames, t_used, exact = 0, 0, 0.0, True
+    while done < E.shape[0] and t_used < seconds:
+        e = E[done].float().cpu().numpy()
+        t0 = time.perf_counter()
+        st, ll = vo.decode_numpy(logA_T, log_pi, e)
+        t_used += time.perf_counter() - t0
+        exact &= bool(np.array_equal(st, gpu_states[done].cpu().numpy())) and np.float32(ll) == np.float32(gpu_loglik[done].item())
+        frames += T
+        done += 1
+    out = {"value": frames / t_used / 1e6, "unit": "Mframes/s", "cores": 1, "kind": "port",
+           "sample": f"first {done} of the batch's songs, T={T}, NumPy float32 loop (oracle/viterbi_oracle.py::decode_numpy)",
+           "bit_exact_vs_gpu": exact, "numpy": np.__version__}
+    nthr = min(vo.num_threads(), 16)
+    nb = min(E.shape[0], nthr)
+    e = E[:nb].float().cpu().numpy()
+    t0 = time.perf_counter()
+    st, ll = vo.decode_c(logA_T, log_pi, e, threads=nthr)
+    dt = time.perf_counter() - t0
+    exact_c = bool(np.array_equal(st, gpu_states[:nb].cpu().numpy())) and bool(np.array_equal(ll, gpu_loglik[:nb].cpu().numpy()))
+    out_c = {"value": nb * T / dt / 1e6, "unit": "Mframes/s", "cores": nthr, "kind": "port",
+             "sample": f"{nb} songs, T={T}, scalar C restatement, one song per thread (oracle/viterbi_oracle.c)",
+             "bit_exact_vs_gpu": exact_c}
+    return out, out_c
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    B, T, S = args.batch, args.frames, args.states
+    logA_T, log_pi = make_params(args)
+    dec = ViterbiDecoder(logA_T, log_pi, dev)
+    algo = args.algo
+    if algo == "auto":
+        algo = "banded" if dec.info["banded_ok"] else "dense"
+    gen = synth.emissions_peaks if args.emissions == "peaks" else synth.emissions_dense
+    dt = torch.float16 if args.f16 else torch.float32
+    E = gen(B, T, S, seed=1234, device=dev, dtype=dt, first_song=rank * B)
+    states = torch.empty((B, T), dtype=torch.int32, device=dev)
+    loglik = torch.empty((B,), dtype=torch.float32, device=dev)
+    n_total = B * world
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        dec.decode_into(E, states, loglik, algo=algo, phase="forward")
+        if ev is not None:
+            ev[1].record()
+        dec.decode_into(E, states, loglik, algo=algo, phase="backtrace")
+        if ev is not None:
+            ev[2].record()
+        if world > 1:
+            return sharded.gather_paths(states, loglik, n_total, dst=0)
+        return states, loglik
+
+    for _ in range(args.warmup):
+        step()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
+    bt_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
+
+    if rank == 0:
+        esize = 2 if args.f16 else 4
+        frames_per_launch = B * T
+        fwd_bytes = frames_per_launch * (S * esize + S * 2)          # emission row in, uint16 back-pointer row out
+        bt_bytes = frames_per_launch * (2 + 4)                       # one back-pointer in, one int32 state out
+        value = n_total * T * args.steps / elapsed / 1e6
+        achieved = fwd_bytes / (fwd_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                rec = json.load(open(tf))
+                key = f"{algo}_B{B}_T{T}_S{S}_{'f16' if args.f16 else 'f32'}"
+                traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Viterbi Mframes/s at S=361 T=30k; achieved HBM GB/s vs peak",
+            "value": value, "unit": "Mframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"batch of {B} songs per GPU, T={T}, S={S}, {'fp16' if args.f16 else 'fp32'} log-emissions "
+                                   f"(BASELINE configs[2]; configs[3] at 8 GPUs), forward + back-trace"
+                                   + (" + RCCL gather of paths" if world > 1 else ""),
+                       "songs_per_gpu": B, "frames": T, "states": S, "emissions": args.emissions,
+                       "transition": args.transition, "forward_kernel": algo, "plan": dec.info},
+            "roofline": {"bound": "hbm", "kernel": f"{algo}_forward_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": fwd_bytes, "avg_launch_ms": fwd_ms,
+                         "bytes_per_frame": S * esize + S * 2,
+                         "note": "dense/banded recursions are fp32-VALU/latency bound, not HBM bound (DESIGN.md)"},
+            "kernels_ms": {"forward": fwd_ms, "backtrace": bt_ms},
+            "whole_path_bytes_per_frame": S * esize + S * 2 + 6,
+            "whole_path_hbm_frac": value * 1e6 * (S * esize + S * 2 + 6) / 1e9 / (HBM_PEAK_GBS * world),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            step()
+            torch.cuda.synchronize()
+            cb, cbc = cpu_baseline(logA_T, log_pi, E, states, loglik, args.cpu_seconds)
+            out["cpu_baseline"] = cb
+            out["cpu_baseline_c"] = cbc
+            out["gpu_over_cpu_1core"] = value / cb["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -123,7 +123,7 @@ def replay_banded(plan: HostPlan, logE):
                     av, ai = sv[qs], si[qs]
                 for k, x in enumerate(plan.extras):
                     v = np.float32(delta[x] + plan.extraA[k, j])
-                    if v > av or (v == av and x < ai):
+                    if v > av or (v == av and x < ai and ai != BIG):
                         av, ai = v, x
             else:
                 d = kind[j]

@@ -312,7 +312,8 @@ __global__ void __launch_bounds__(banded_max_threads(W)) banded_forward_kernel(F
             }
 #pragma unroll
             for (int k = 0; k < kMaxExtras; ++k)
-                if (k < nx && (xv[k] > acc.v || (xv[k] == acc.v && xcol[k] < acc.i))) acc = VI{xv[k], xcol[k]};
+                if (k < nx && (xv[k] > acc.v || (xv[k] == acc.v && xcol[k] < acc.i && acc.i != kBig)))
+                    acc = VI{xv[k], xcol[k]};  // acc.i == kBig <=> everything so far is -inf: stays "none" -> 0
         } else if (kind >= 0) {
             for (int b = 0; b < nw; ++b) acc = op_fwd(acc, dtot[kind * 16 + b]);
         }
@@ -376,7 +377,6 @@ __global__ void __launch_bounds__(kBtThreads) backtrace_kernel(BtArgs a) {
     while (hi >= 1) {
         const int first = hi - K + 1 > 1 ? hi - K + 1 : 1;
         const int rows = hi - first + 1;
-        const int nvec = rows * rowv;
         __syncthreads();  // previous tile fully consumed
 #pragma unroll
         for (int v = 0; v < kBtMaxVec; ++v) tile[tid + v * kBtThreads] = stage[v];  // slots >= nvec hold clamped copies
