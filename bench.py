@@ -70,7 +70,7 @@ def cpu_baseline(logA_T, log_pi, E, gpu_states, gpu_loglik, seconds):
         t0 = time.perf_counter()
         st, ll = vo.decode_numpy(logA_T, log_pi, e)
         t_used += time.perf_counter() - t0
-        exact &= bool(np.array_equal(st, gpu_states[done].cpu().numpy())) and np.float32(ll) == np.float32(gpu_loglik[done].item())
+        exact = exact and bool(np.array_equal(st, gpu_states[done].cpu().numpy())) and bool(np.float32(ll) == np.float32(gpu_loglik[done].item()))
         frames += T
         done += 1
     out = {"value": frames / t_used / 1e6, "unit": "Mframes/s", "cores": 1, "kind": "port",

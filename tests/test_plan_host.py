@@ -20,7 +20,7 @@ def test_tonet_structure_is_proven(golden):
 def test_msnet_real_parameters_are_banded(golden):
     p = golden["params"]
     plan = HostPlan(p["msnet321_logA_T"], p["msnet321_log_pi"])
-    assert plan.ok and plan.max_window == 25 and plan.W == 28
+    assert plan.ok and plan.max_window == 25 and plan.W == 32
     assert plan.extras == [320] and plan.dense_rows == [320]
 
 

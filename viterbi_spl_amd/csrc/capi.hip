@@ -132,7 +132,7 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
     if (!logE) return VIT_EINVAL;
     if (emis_dtype != VIT_F32 && emis_dtype != VIT_F16) return VIT_EINVAL;
     if (B == 0) return VIT_OK;
-    const bool banded_possible = plan->bp.ok && plan->L.SP <= vit::banded_max_threads(plan->bp.W);
+    const bool banded_possible = plan->bp.ok && vit::banded_target_waves(plan->S, plan->bp.W) > 0;
     if (algo == VIT_ALGO_AUTO) algo = banded_possible ? VIT_ALGO_BANDED : VIT_ALGO_DENSE;
     if (algo == VIT_ALGO_BANDED && !banded_possible) return VIT_EUNSUPPORTED;
     if (algo != VIT_ALGO_BANDED && algo != VIT_ALGO_DENSE) return VIT_EINVAL;

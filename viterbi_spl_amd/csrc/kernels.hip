@@ -193,139 +193,198 @@ __global__ void __launch_bounds__(dense_max_threads(NS)) dense_forward_kernel(Fw
 }
 
 // ---------------------------------------------------------------------------------------
-// Banded forward kernel: one song per workgroup, one thread per target.
+// Banded forward kernel: one song per workgroup.
+//
 // Per frame, for a banded target j (window [lo_j, lo_j+W), shared constant c0, extra
 // columns X) the candidates, merged in increasing source order with strict '>':
-//   prefix  first-max_{i < lo_j, i not in X}  fl(delta_i + c0)     (prefix scan, evaluated at lo_j-1)
-//   window  fl(delta_i + logA_T[j][i]),  i in [lo_j, lo_j+W)       (W register-resident entries)
-//   suffix  first-max_{i >= lo_j+W, i not in X} fl(delta_i + c0)   (suffix scan, evaluated at lo_j+W)
-//   extras  fl(delta_x + logA_T[j][x]), x in X                     (lexicographic merge)
-// Dense rows (e.g. the "unvoiced" target) are reduced over all sources by the whole workgroup.
-// Two workgroup barriers per frame; delta, the scan arrays and wave totals live in LDS.
+//   prefix  first-max_{i < lo_j, i not in X}  fl(delta_i + c0)      Pp[lo_j]
+//   window  fl(delta_i + logA_T[j][i]),  i in [lo_j, lo_j+W)        W register-resident entries
+//   suffix  first-max_{i >= lo_j+W, i not in X} fl(delta_i + c0)    Sf[lo_j+W]
+//   extras  fl(delta_x + logA_T[j][x]), x in X                      lexicographic merge
+// Dense rows (e.g. the "unvoiced" target) are reduced over all sources.
+//
+// Wave roles (NWT = target waves, 64*NWT >= S):
+//   waves 0..NWT-1  one thread per target: window candidates, merge, delta_t, back-pointer
+//   wave  NWT       prefix scan over all sources (NWT elements per lane) + dense rows 0,2
+//   wave  NWT+1     suffix scan (lanes hold the sources in descending blocks) + dense rows 1,3
+// The scan waves run beside the window phase; two workgroup barriers per frame.
 // ---------------------------------------------------------------------------------------
-template <int W, typename ET>
-__global__ void __launch_bounds__(banded_max_threads(W)) banded_forward_kernel(FwdArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int S = a.S, SP = a.SP, T = a.T;
-    const int NP = blockDim.x;  // == SP
-    const int nw = NP >> 6;
-    float* dl = reinterpret_cast<float*>(smem);       // [NP]
-    VI* pw = reinterpret_cast<VI*>(dl + NP);          // [NP] wave-local inclusive prefix scan
-    VI* sw = pw + NP;                                 // [NP] wave-local inclusive suffix scan
-    VI* ptot = sw + NP;                               // [16]
-    VI* stot = ptot + 16;                             // [16]
-    VI* dtot = stot + 16;                             // [kMaxDense][16]
+template <int CTRL>
+__device__ __forceinline__ VI dpp_shift_in(VI x) {  // whole-wave shift by one lane, lane 0 gets identity
+    VI r;
+    r.v = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-INFINITY), __float_as_int(x.v), CTRL, 0xf, 0xf, false));
+    r.i = __builtin_amdgcn_update_dpp(kBig, x.i, CTRL, 0xf, 0xf, false);
+    return r;
+}
 
-    const int j = threadIdx.x;
-    const int lane = j & 63, wv = j >> 6;
-    const int jr = NP - 1 - j;  // source handled by this thread in the reversed scan
+template <int W, int NWT, typename ET>
+__global__ void __launch_bounds__((NWT + 2) * 64) banded_forward_kernel(FwdArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int NP = NWT * 64;   // padded state count handled by the target waves
+    constexpr int EPL = NWT;       // sources per lane in the scan waves
+    const int S = a.S, SP = a.SP, T = a.T;
+    float* dl = reinterpret_cast<float*>(smem);   // [NP]       delta_{t-1}; entries >= S stay -inf
+    VI* Pp = reinterpret_cast<VI*>(dl + NP);      // [NP+1]     Pp[q] = first-max over sources < q
+    VI* Sf = Pp + NP + 1;                         // [NP+1]     Sf[q] = first-max over sources >= q
+    VI* Dr = Sf + NP + 1;                         // [4]        dense-row results
+    VI* tot = Dr + kMaxDenseRows;                 // [16]       terminal argmax scratch
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
     const int song = blockIdx.x;
     const int Tb = song_length(a.lengths, song, T);
     const ET* __restrict__ E = reinterpret_cast<const ET*>(a.logE) + (size_t)song * T * S;
     uint16_t* __restrict__ psi = a.psi + (size_t)song * T * a.SPSI;
     const float c0 = a.c0;
     const int nx = a.n_extras, nd = a.n_dense;
-
-    const int lo = reinterpret_cast<const int32_t*>(a.image + a.off_lo)[j];
-    const int kind = reinterpret_cast<const int32_t*>(a.image + a.off_kind)[j];
-    const float* __restrict__ tab = reinterpret_cast<const float*>(a.image + a.off_tabA);
-    const float* __restrict__ xaT = reinterpret_cast<const float*>(a.image + a.off_extraA);
     const float* __restrict__ daT = reinterpret_cast<const float*>(a.image + a.off_denseA);
 
+    // ---------------- per-role setup
+    const bool is_target = wv < NWT;
+    const int j = tid;                       // target index (target waves)
+    const bool tvalid = is_target && j < S;
+    const int jc = j < SP ? j : 0;           // clamp for image reads (image rows are SP wide)
+    int lo = 0, kind = -2;
     float aw[W];
-#pragma unroll
-    for (int w = 0; w < W; ++w) aw[w] = tab[(size_t)w * SP + j];
-    float xa[kMaxExtras], da[kMaxDenseRows];
+    float xa[kMaxExtras];
     int xcol[kMaxExtras];
-    bool masked = j >= S, masked_r = jr >= S;
 #pragma unroll
-    for (int k = 0; k < kMaxExtras; ++k) {
-        xa[k] = xaT[(size_t)k * SP + j];
-        xcol[k] = a.extras[k];
-        if (k < nx) { masked |= (j == xcol[k]); masked_r |= (jr == xcol[k]); }
+    for (int k = 0; k < kMaxExtras; ++k) { xa[k] = -INFINITY; xcol[k] = a.extras[k]; }
+    if (is_target) {
+        lo = reinterpret_cast<const int32_t*>(a.image + a.off_lo)[jc];
+        kind = j < SP ? reinterpret_cast<const int32_t*>(a.image + a.off_kind)[jc] : -2;
+        const float* __restrict__ tab = reinterpret_cast<const float*>(a.image + a.off_tabA);
+        const float* __restrict__ xaT = reinterpret_cast<const float*>(a.image + a.off_extraA);
+#pragma unroll
+        for (int w = 0; w < W; ++w) aw[w] = tab[(size_t)w * SP + jc];
+#pragma unroll
+        for (int k = 0; k < kMaxExtras; ++k) xa[k] = xaT[(size_t)k * SP + jc];
+    } else {
+#pragma unroll
+        for (int w = 0; w < W; ++w) aw[w] = 0.f;
     }
+    // scan waves: lane owns sources [blk*EPL, blk*EPL+EPL); the suffix wave walks blocks downwards
+    const bool is_pre = wv == NWT;
+    const int blk = is_pre ? lane : 63 - lane;
+    const int i0 = blk * EPL;
+    bool smask[EPL];           // source is padding or an extra column: excluded from the c0 scans
+    float dA0[EPL], dA1[EPL];  // this wave's two dense rows
 #pragma unroll
-    for (int d = 0; d < kMaxDenseRows; ++d) da[d] = daT[(size_t)d * SP + j];
+    for (int e = 0; e < EPL; ++e) {
+        const int i = i0 + e;
+        bool m = i >= S;
+#pragma unroll
+        for (int k = 0; k < kMaxExtras; ++k) m |= (k < nx && i == xcol[k]);
+        smask[e] = m;
+        const int d0 = is_pre ? 0 : 1;
+        dA0[e] = (!is_target && i < S && d0 < nd) ? daT[(size_t)d0 * SP + i] : -INFINITY;
+        dA1[e] = (!is_target && i < S && d0 + 2 < nd) ? daT[(size_t)(d0 + 2) * SP + i] : -INFINITY;
+    }
 
-    {
+    // ---------------- frame 0
+    if (is_target) {
         float d = -INFINITY;
-        if (j < S) d = reinterpret_cast<const float*>(a.image + a.off_logpi)[j] + load_e<ET>(E + j);
+        if (tvalid) d = reinterpret_cast<const float*>(a.image + a.off_logpi)[j] + load_e<ET>(E + j);
         dl[j] = d;
+    } else if (lane == 0) {
+        if (is_pre) Pp[0] = vi_identity(); else Sf[NP] = vi_identity();
     }
-    float enext = (j < S && Tb > 1) ? load_e<ET>(E + S + j) : 0.f;
+    float enext = (tvalid && Tb > 1) ? load_e<ET>(E + S + j) : 0.f;
     __syncthreads();
 
     for (int t = 1; t < Tb; ++t) {
-        const float ecur = enext;
-        if (j < S && t + 1 < Tb) enext = load_e<ET>(E + (size_t)(t + 1) * S + j);
-
-        // ---- phase 1: everything that reads delta_{t-1}
-        const float dj = dl[j];
-        const float djr = dl[jr];
-        {
-            VI x{masked ? -INFINITY : dj + c0, masked ? kBig : j};
-            x = wave_scan<false>(x);
-            pw[j] = x;
-            if (lane == 63) ptot[wv] = x;
-            VI y{masked_r ? -INFINITY : djr + c0, masked_r ? kBig : jr};
-            y = wave_scan<true>(y);
-            sw[jr] = y;
-            if (lane == 63) stot[wv] = y;
-        }
-#pragma unroll
-        for (int d = 0; d < kMaxDenseRows; ++d) {
-            if (d < nd) {
-                VI z{dj + da[d], j < S ? j : kBig};
-                z = wave_scan<false>(z);
-                if (lane == 63) dtot[d * 16 + wv] = z;
-            }
-        }
+        float ecur = 0.f, best = -INFINITY;
+        int arg = kBig;
         float xv[kMaxExtras];
 #pragma unroll
-        for (int k = 0; k < kMaxExtras; ++k) xv[k] = (k < nx) ? dl[xcol[k]] + xa[k] : -INFINITY;
+        for (int k = 0; k < kMaxExtras; ++k) xv[k] = -INFINITY;
 
-        float best = -INFINITY;
-        int arg = kBig;
+        if (is_target) {
+            // ---- window candidates (everything here reads delta_{t-1})
+            ecur = enext;
+            if (tvalid && t + 1 < Tb) enext = load_e<ET>(E + (size_t)(t + 1) * S + j);
 #pragma unroll
-        for (int w = 0; w < W; ++w) {
-            const float v = dl[lo + w] + aw[w];
-            if (v > best) { best = v; arg = w; }
+            for (int k = 0; k < kMaxExtras; ++k)
+                if (k < nx) xv[k] = dl[xcol[k]] + xa[k];
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const float v = dl[lo + w] + aw[w];
+                if (v > best) { best = v; arg = w; }
+            }
+        } else {
+            float d[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) d[e] = dl[i0 + e];
+            VI p[EPL];
+            if (is_pre) {
+                // inclusive first-max prefix over this lane's sources, ascending
+                VI run = vi_identity();
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    const VI x{smask[e] ? -INFINITY : d[e] + c0, smask[e] ? kBig : i0 + e};
+                    run = op_fwd(run, x);
+                    p[e] = run;
+                }
+                const VI ex = dpp_shift_in<0x138>(wave_scan<false>(run));  // sources of all lower lanes
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) Pp[i0 + e + 1] = op_fwd(ex, p[e]);
+            } else {
+                // inclusive first-max suffix over this lane's sources, descending
+                VI run = vi_identity();
+#pragma unroll
+                for (int e = EPL - 1; e >= 0; --e) {
+                    const VI x{smask[e] ? -INFINITY : d[e] + c0, smask[e] ? kBig : i0 + e};
+                    run = op_rev(run, x);
+                    p[e] = run;
+                }
+                const VI ex = dpp_shift_in<0x138>(wave_scan<true>(run));   // sources of all higher blocks
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) Sf[i0 + e] = op_rev(ex, p[e]);
+            }
+            // dense rows: full first-max over every source
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int dr = (is_pre ? 0 : 1) + 2 * r;
+                if (dr < nd) {
+                    VI run = vi_identity();
+                    if (is_pre) {
+#pragma unroll
+                        for (int e = 0; e < EPL; ++e)
+                            run = op_fwd(run, VI{d[e] + (r ? dA1[e] : dA0[e]), i0 + e < S ? i0 + e : kBig});
+                        run = wave_scan<false>(run);
+                    } else {
+#pragma unroll
+                        for (int e = EPL - 1; e >= 0; --e)
+                            run = op_rev(run, VI{d[e] + (r ? dA1[e] : dA0[e]), i0 + e < S ? i0 + e : kBig});
+                        run = wave_scan<true>(run);
+                    }
+                    if (lane == 63) Dr[dr] = run;
+                }
+            }
         }
         __syncthreads();
 
-        // ---- phase 2: merge, write delta_t and the back-pointer
-        VI acc = vi_identity();
-        if (kind == -1) {
-            if (lo > 0) {
-                const int q = lo - 1, pb = q >> 6;
-                for (int b = 0; b < nw; ++b) if (b < pb) acc = op_fwd(acc, ptot[b]);
-                acc = op_fwd(acc, pw[q]);
-            }
+        if (is_target) {
+            // ---- merge in increasing source order, write delta_t and the back-pointer
+            VI acc = Pp[lo];
             acc = op_fwd(acc, VI{best, arg == kBig ? kBig : lo + arg});
-            const int qs = lo + W;
-            if (qs < S) {
-                const int rb = (NP - 1 - qs) >> 6;
-                VI sacc = vi_identity();
-                for (int b = 0; b < nw; ++b) if (b < rb) sacc = op_rev(sacc, stot[b]);
-                sacc = op_rev(sacc, sw[qs]);
-                acc = op_fwd(acc, sacc);
-            }
+            acc = op_fwd(acc, Sf[lo + W]);
 #pragma unroll
             for (int k = 0; k < kMaxExtras; ++k)
                 if (k < nx && (xv[k] > acc.v || (xv[k] == acc.v && xcol[k] < acc.i && acc.i != kBig)))
                     acc = VI{xv[k], xcol[k]};  // acc.i == kBig <=> everything so far is -inf: stays "none" -> 0
-        } else if (kind >= 0) {
-            for (int b = 0; b < nw; ++b) acc = op_fwd(acc, dtot[kind * 16 + b]);
-        }
-        if (j < S) {
-            if (acc.i == kBig) acc.i = 0;
-            dl[j] = acc.v + ecur;
-            psi[(size_t)t * a.SPSI + j] = (uint16_t)acc.i;
+            const VI dres = Dr[kind >= 0 ? kind : 0];
+            if (kind >= 0) acc = dres;
+            if (tvalid) {
+                if (acc.i == kBig) acc.i = 0;
+                dl[j] = acc.v + ecur;
+                psi[(size_t)t * a.SPSI + j] = (uint16_t)acc.i;
+            }
         }
         __syncthreads();
     }
 
-    terminal_argmax(dl[j], j, S, ptot, nw, a.last_state, a.loglik, song);
+    terminal_argmax(is_target ? dl[j] : -INFINITY, tid, S, tot, NWT + 2, a.last_state, a.loglik, song);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -442,24 +501,43 @@ hipError_t launch_dense(const FwdArgs& a, int ns, bool f16, hipStream_t st) {
     return launch_dense_t<1, float>(a, st);
 }
 
-template <int W, typename ET>
+template <int W, int NWT, typename ET>
 static hipError_t launch_banded_t(const FwdArgs& a, hipStream_t st) {
-    if (a.SP > banded_max_threads(W)) return hipErrorInvalidConfiguration;
-    const size_t lds = sizeof(float) * a.SP + sizeof(VI) * (2 * a.SP + 32 + 16 * kMaxDenseRows);
-    hipLaunchKernelGGL((banded_forward_kernel<W, ET>), dim3((int)a.B), dim3(a.SP), lds, st, a);
+    constexpr int NP = NWT * 64;
+    const size_t lds = sizeof(float) * NP + sizeof(VI) * (2 * (NP + 1) + kMaxDenseRows + 16);
+    hipLaunchKernelGGL((banded_forward_kernel<W, NWT, ET>), dim3((int)a.B), dim3((NWT + 2) * 64), lds, st, a);
     return hipGetLastError();
+}
+
+template <int W, typename ET>
+static hipError_t launch_banded_w(const FwdArgs& a, hipStream_t st) {
+    const int nwt = banded_target_waves(a.S, W);
+    if constexpr (W <= 32) {
+        switch (nwt) {
+            case 2: return launch_banded_t<W, 2, ET>(a, st);
+            case 4: return launch_banded_t<W, 4, ET>(a, st);
+            case 6: return launch_banded_t<W, 6, ET>(a, st);
+            case 8: return launch_banded_t<W, 8, ET>(a, st);
+            case 12: return launch_banded_t<W, 12, ET>(a, st);
+            default: return hipErrorInvalidConfiguration;
+        }
+    } else {
+        switch (nwt) {
+            case 2: return launch_banded_t<W, 2, ET>(a, st);
+            case 4: return launch_banded_t<W, 4, ET>(a, st);
+            case 6: return launch_banded_t<W, 6, ET>(a, st);
+            default: return hipErrorInvalidConfiguration;
+        }
+    }
 }
 
 template <typename ET>
 static hipError_t launch_banded_e(const FwdArgs& a, hipStream_t st) {
     switch (a.W) {
-        case 16: return launch_banded_t<16, ET>(a, st);
-        case 28: return launch_banded_t<28, ET>(a, st);
-        case 32: return launch_banded_t<32, ET>(a, st);
-        case 64: return launch_banded_t<64, ET>(a, st);
-        case 96: return launch_banded_t<96, ET>(a, st);
-        case 128: return launch_banded_t<128, ET>(a, st);
-        default: return hipErrorInvalidValue;
+        case 16: return launch_banded_w<16, ET>(a, st);
+        case 32: return launch_banded_w<32, ET>(a, st);
+        case 64: return launch_banded_w<64, ET>(a, st);
+        default: return hipErrorInvalidConfiguration;
     }
 }
 

@@ -8,9 +8,17 @@
 
 namespace vit {
 
-// threads per workgroup the banded kernel may be launched with for window width W
-// (bounds the VGPR budget: W register-resident transition entries per thread)
-constexpr int banded_max_threads(int W) { return W <= 32 ? 1024 : (W <= 64 ? 512 : 256); }
+// Banded kernel geometry: NWT target waves (64*NWT >= S) plus two scan waves.  Returns the
+// number of target waves for (S, W), or 0 when the combination is not instantiated
+// (W register-resident transition entries per thread bound the workgroup size).
+constexpr int banded_target_waves(int S, int W) {
+    const int need = (S + 63) / 64;
+    const int opts[5] = {2, 4, 6, 8, 12};
+    const int nopts = W <= 32 ? 5 : (W <= 64 ? 3 : 0);
+    for (int k = 0; k < nopts; ++k)
+        if (opts[k] >= need) return opts[k];
+    return 0;
+}
 // the dense kernel keeps NS running (best, arg) pairs per thread
 constexpr int dense_max_threads(int NS) { return NS <= 2 ? 1024 : 512; }
 
