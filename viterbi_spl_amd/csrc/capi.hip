@@ -1,6 +1,7 @@
 // capi.hip -- extern "C" entry points declared in include/viterbi_hip.h.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -157,6 +158,7 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
     a.n_dense = plan->bp.ok ? plan->bp.n_dense : 0;
     for (int k = 0; k < vit::kMaxExtras; ++k) a.extras[k] = plan->bp.extras[k];
     a.c0 = plan->bp.c0;
+    if (const char* dbg = std::getenv("VIT_DEBUG_FLAGS")) a.debug = std::atoi(dbg);  // timing experiments only
     a.off_logpi = plan->L.off_logpi;
     a.off_A4 = plan->L.off_A4;
     a.off_lo = plan->L.off_lo;

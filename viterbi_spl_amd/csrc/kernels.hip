@@ -237,6 +237,7 @@ __global__ void __launch_bounds__((NWT + 2) * 64) banded_forward_kernel(FwdArgs 
     uint16_t* __restrict__ psi = a.psi + (size_t)song * T * a.SPSI;
     const float c0 = a.c0;
     const int nx = a.n_extras, nd = a.n_dense;
+    const int dbg = a.debug;
     const float* __restrict__ daT = reinterpret_cast<const float*>(a.image + a.off_denseA);
 
     // ---------------- per-role setup
@@ -289,11 +290,24 @@ __global__ void __launch_bounds__((NWT + 2) * 64) banded_forward_kernel(FwdArgs 
     } else if (lane == 0) {
         if (is_pre) Pp[0] = vi_identity(); else Sf[NP] = vi_identity();
     }
-    float enext = (tvalid && Tb > 1) ? load_e<ET>(E + S + j) : 0.f;
+    // Emission rows are fetched two frames ahead and consumed only at the end of a frame: vmcnt
+    // retires in order, so a wait on a younger load would also wait for the previous frame's
+    // back-pointer store.
+    float e_a = (tvalid && Tb > 1) ? load_e<ET>(E + S + j) : 0.f;
+    float e_b = (tvalid && Tb > 2) ? load_e<ET>(E + 2 * (size_t)S + j) : 0.f;
+    // Retire every set-up load here, so that inside the frame loop the only vector-memory
+    // operations the wait-count pass has to reason about are the two it issues per frame.
+#pragma unroll
+    for (int w = 0; w < W; ++w) asm volatile("" ::"v"(aw[w]));
+#pragma unroll
+    for (int k = 0; k < kMaxExtras; ++k) asm volatile("" ::"v"(xa[k]));
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) asm volatile("" ::"v"(dA0[e]), "v"(dA1[e]));
+    asm volatile("" ::"v"(lo), "v"(kind), "v"(e_a), "v"(e_b));
     __syncthreads();
 
-    for (int t = 1; t < Tb; ++t) {
-        float ecur = 0.f, best = -INFINITY;
+    auto frame = [&](const int t, float& e_slot) {
+        float best = -INFINITY;
         int arg = kBig;
         float xv[kMaxExtras];
 #pragma unroll
@@ -301,17 +315,17 @@ __global__ void __launch_bounds__((NWT + 2) * 64) banded_forward_kernel(FwdArgs 
 
         if (is_target) {
             // ---- window candidates (everything here reads delta_{t-1})
-            ecur = enext;
-            if (tvalid && t + 1 < Tb) enext = load_e<ET>(E + (size_t)(t + 1) * S + j);
 #pragma unroll
             for (int k = 0; k < kMaxExtras; ++k)
                 if (k < nx) xv[k] = dl[xcol[k]] + xa[k];
+            if (!(dbg & 1)) {
 #pragma unroll
-            for (int w = 0; w < W; ++w) {
-                const float v = dl[lo + w] + aw[w];
-                if (v > best) { best = v; arg = w; }
+                for (int w = 0; w < W; ++w) {
+                    const float v = dl[lo + w] + aw[w];
+                    if (v > best) { best = v; arg = w; }
+                }
             }
-        } else {
+        } else if (!(dbg & 2)) {
             float d[EPL];
 #pragma unroll
             for (int e = 0; e < EPL; ++e) d[e] = dl[i0 + e];
@@ -364,7 +378,7 @@ __global__ void __launch_bounds__((NWT + 2) * 64) banded_forward_kernel(FwdArgs 
         }
         __syncthreads();
 
-        if (is_target) {
+        if (is_target && !(dbg & 4)) {
             // ---- merge in increasing source order, write delta_t and the back-pointer
             VI acc = Pp[lo];
             acc = op_fwd(acc, VI{best, arg == kBig ? kBig : lo + arg});
@@ -377,12 +391,21 @@ __global__ void __launch_bounds__((NWT + 2) * 64) banded_forward_kernel(FwdArgs 
             if (kind >= 0) acc = dres;
             if (tvalid) {
                 if (acc.i == kBig) acc.i = 0;
-                dl[j] = acc.v + ecur;
-                psi[(size_t)t * a.SPSI + j] = (uint16_t)acc.i;
+                dl[j] = acc.v + e_slot;
+                if (!(dbg & 8)) {
+                    psi[(size_t)t * a.SPSI + j] = (uint16_t)acc.i;
+                    if (t + 2 < Tb) e_slot = load_e<ET>(E + (size_t)(t + 2) * S + j);
+                }
             }
         }
         __syncthreads();
+    };
+    int t = 1;
+    for (; t + 1 < Tb; t += 2) {
+        frame(t, e_a);
+        frame(t + 1, e_b);
     }
+    if (t < Tb) frame(t, e_a);
 
     terminal_argmax(is_target ? dl[j] : -INFINITY, tid, S, tot, NWT + 2, a.last_state, a.loglik, song);
 }

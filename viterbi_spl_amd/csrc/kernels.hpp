@@ -34,6 +34,7 @@ struct FwdArgs {
     int n_extras, n_dense;
     int extras[kMaxExtras];
     float c0;
+    int debug;              // timing-only ablation mask (VIT_DEBUG_FLAGS); 0 in production
     size_t off_logpi, off_A4, off_lo, off_kind, off_tabA, off_extraA, off_denseA;
 };
 
