@@ -100,8 +100,9 @@ int vit_plan_query(const vit_plan *plan, vit_plan_info *info);
 size_t vit_plan_image_bytes(const vit_plan *plan);
 int vit_plan_upload(vit_plan *plan, void *device_image, size_t bytes, vit_stream stream);
 
-/* Bytes of device workspace vit_decode() needs for a [B,T,S] batch (back-pointers
- * as uint16 + per-song terminals).  256-byte aligned base required. */
+/* Bytes of device workspace vit_decode() needs for a [B,T,S] batch (float32 delta history
+ * [B,T,ceil(S/4)*4] + per-frame floor maxima [B,T] + per-song terminals).  256-byte aligned
+ * base required. */
 size_t vit_workspace_bytes(const vit_plan *plan, int64_t B, int64_t T);
 
 /*
@@ -117,13 +118,14 @@ int vit_decode(const vit_plan *plan, const void *logE, int emis_dtype, int64_t B
                const int64_t *lengths, void *workspace, size_t workspace_bytes,
                int32_t *states, float *loglik, int algo, vit_stream stream);
 
-/* Forward pass only / back-trace only (same arguments); used by bench.py to time
- * the two kernels separately.  vit_decode() == forward then backtrace. */
+/* Forward pass only / back-trace only; used by bench.py to time the two kernels separately.
+ * vit_decode() == forward then backtrace.  `algo` of vit_backtrace must be the one given to the
+ * vit_forward that filled the workspace. */
 int vit_forward(const vit_plan *plan, const void *logE, int emis_dtype, int64_t B, int64_t T,
                 const int64_t *lengths, void *workspace, size_t workspace_bytes,
                 float *loglik, int algo, vit_stream stream);
 int vit_backtrace(const vit_plan *plan, int64_t B, int64_t T, const int64_t *lengths,
-                  void *workspace, size_t workspace_bytes, int32_t *states, vit_stream stream);
+                  void *workspace, size_t workspace_bytes, int32_t *states, int algo, vit_stream stream);
 
 /* Fused epilogue of Viterbi.__call__ (tonet/for_paper.py:1828-1829):
  * voiced = state < n_bins ; bins = min(state, n_bins-1).  n entries, device pointers.

@@ -34,7 +34,7 @@ class HostPlan:
         h = lib.vph_create(A.ctypes.data, pi.ctypes.data, S)
         info = np.zeros(16, np.int32)
         c0 = np.zeros(1, np.float32)
-        off = np.zeros(8, np.int64)
+        off = np.zeros(9, np.int64)
         lib.vph_info(h, info.ctypes.data, c0.ctypes.data)
         lib.vph_offsets(h, off.ctypes.data)
         img = np.zeros(int(off[7]), np.uint8)
@@ -57,6 +57,7 @@ class HostPlan:
         self.tabA = sec(4, np.float32, max(self.W, 1) * SP).reshape(max(self.W, 1), SP)
         self.extraA = sec(5, np.float32, 4 * SP).reshape(4, SP)
         self.denseA = sec(6, np.float32, 4 * SP).reshape(4, SP)
+        self.Arow = sec(8, np.float32, self.S * SP).reshape(self.S, SP)
 
 
 def _first_max_prefix(g, gi):

@@ -79,7 +79,7 @@ def load() -> ctypes.CDLL:
     lib.vit_forward.restype = i32
     lib.vit_forward.argtypes = [vp, vp, i32, i64, i64, vp, vp, sz, vp, i32, vp]
     lib.vit_backtrace.restype = i32
-    lib.vit_backtrace.argtypes = [vp, i64, i64, vp, vp, sz, vp, vp]
+    lib.vit_backtrace.argtypes = [vp, i64, i64, vp, vp, sz, vp, i32, vp]
     lib.vit_voicing_map.restype = i32
     lib.vit_voicing_map.argtypes = [vp, i64, i32, vp, vp, vp]
     lib.vit_debug_scan.restype = i32

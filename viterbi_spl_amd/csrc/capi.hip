@@ -23,7 +23,7 @@ namespace {
 thread_local int g_last_hip_error = 0;
 
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
-inline int psi_stride(int S) { return (S + 7) / 8 * 8; }
+inline int hist_stride(int S) { return (S + 3) / 4 * 4; }
 
 int hip_fail(hipError_t e) {
     g_last_hip_error = (int)e;
@@ -31,14 +31,16 @@ int hip_fail(hipError_t e) {
 }
 
 struct WsLayout {
-    size_t off_psi, off_last, bytes;
+    size_t off_hist, off_fmax, off_last, off_entry, bytes;
 };
 
 WsLayout ws_layout(int S, int64_t B, int64_t T) {
     WsLayout w;
-    w.off_psi = 0;
-    w.off_last = align256((size_t)B * (size_t)T * psi_stride(S) * sizeof(uint16_t));
-    w.bytes = w.off_last + align256((size_t)B * sizeof(int32_t));
+    w.off_hist = 0;
+    w.off_fmax = align256((size_t)B * (size_t)T * hist_stride(S) * sizeof(float));
+    w.off_last = w.off_fmax + align256((size_t)B * (size_t)T * sizeof(float));
+    w.off_entry = w.off_last + align256((size_t)B * sizeof(int32_t));
+    w.bytes = w.off_entry + align256((size_t)B * vit::kBtMaxChunks * sizeof(int32_t));
     return w;
 }
 
@@ -125,6 +127,14 @@ size_t vit_workspace_bytes(const vit_plan* plan, int64_t B, int64_t T) {
     return ws_layout(plan->S, B, T).bytes;
 }
 
+static int resolve_algo(const vit_plan* plan, int algo) {
+    const bool banded_possible = plan->bp.ok && vit::banded_target_waves(plan->S, plan->bp.W) > 0;
+    if (algo == VIT_ALGO_AUTO) return banded_possible ? VIT_ALGO_BANDED : VIT_ALGO_DENSE;
+    if (algo == VIT_ALGO_BANDED) return banded_possible ? VIT_ALGO_BANDED : VIT_EUNSUPPORTED;
+    if (algo == VIT_ALGO_DENSE) return VIT_ALGO_DENSE;
+    return VIT_EINVAL;
+}
+
 int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t B, int64_t T,
                 const int64_t* lengths, void* workspace, size_t workspace_bytes, float* loglik, int algo,
                 vit_stream stream) {
@@ -133,10 +143,8 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
     if (!logE) return VIT_EINVAL;
     if (emis_dtype != VIT_F32 && emis_dtype != VIT_F16) return VIT_EINVAL;
     if (B == 0) return VIT_OK;
-    const bool banded_possible = plan->bp.ok && vit::banded_target_waves(plan->S, plan->bp.W) > 0;
-    if (algo == VIT_ALGO_AUTO) algo = banded_possible ? VIT_ALGO_BANDED : VIT_ALGO_DENSE;
-    if (algo == VIT_ALGO_BANDED && !banded_possible) return VIT_EUNSUPPORTED;
-    if (algo != VIT_ALGO_BANDED && algo != VIT_ALGO_DENSE) return VIT_EINVAL;
+    algo = resolve_algo(plan, algo);
+    if (algo < 0) return algo;
 
     const WsLayout w = ws_layout(plan->S, B, T);
     uint8_t* ws = static_cast<uint8_t*>(workspace);
@@ -144,7 +152,8 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
     a.image = plan->dev_image;
     a.logE = logE;
     a.lengths = lengths;
-    a.psi = reinterpret_cast<uint16_t*>(ws + w.off_psi);
+    a.hist = reinterpret_cast<float*>(ws + w.off_hist);
+    a.fmax = reinterpret_cast<float*>(ws + w.off_fmax);
     a.last_state = reinterpret_cast<int32_t*>(ws + w.off_last);
     a.loglik = loglik;
     a.B = B;
@@ -152,7 +161,7 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
     a.S = plan->S;
     a.SP = plan->L.SP;
     a.S4 = plan->L.S4;
-    a.SPSI = psi_stride(plan->S);
+    a.SD = hist_stride(plan->S);
     a.W = plan->bp.W;
     a.n_extras = plan->bp.ok ? plan->bp.n_extras : 0;
     a.n_dense = plan->bp.ok ? plan->bp.n_dense : 0;
@@ -178,21 +187,50 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
 }
 
 int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* lengths, void* workspace,
-                  size_t workspace_bytes, int32_t* states, vit_stream stream) {
+                  size_t workspace_bytes, int32_t* states, int algo, vit_stream stream) {
     int rc = check_common(plan, B, T, workspace, workspace_bytes);
     if (rc != VIT_OK) return rc;
     if (!states) return VIT_EINVAL;
+    algo = resolve_algo(plan, algo);
+    if (algo < 0) return algo;
     if (B == 0) return VIT_OK;
     const WsLayout w = ws_layout(plan->S, B, T);
     uint8_t* ws = static_cast<uint8_t*>(workspace);
     vit::BtArgs b{};
-    b.psi = reinterpret_cast<const uint16_t*>(ws + w.off_psi);
+    b.image = plan->dev_image;
+    b.hist = reinterpret_cast<const float*>(ws + w.off_hist);
+    b.fmax = reinterpret_cast<const float*>(ws + w.off_fmax);
     b.last_state = reinterpret_cast<const int32_t*>(ws + w.off_last);
     b.lengths = lengths;
     b.states = states;
+    b.entry = reinterpret_cast<int32_t*>(ws + w.off_entry);
+    b.chunks = vit::backtrace_chunks(B, (int)T);
+    b.warm = vit::kBtWarm;
+    // test hooks: force the chunking / warm-up so that the verify-and-repair pass is exercised
+    if (const char* e = std::getenv("VIT_BT_CHUNKS")) { int c = std::atoi(e); if (c >= 1 && c <= vit::kBtMaxChunks) b.chunks = c; }
+    if (const char* e = std::getenv("VIT_BT_WARM")) { int g = std::atoi(e); if (g >= 0) b.warm = g; }
     b.B = B;
     b.T = (int)T;
-    b.SPSI = psi_stride(plan->S);
+    b.S = plan->S;
+    b.SP = plan->L.SP;
+    b.SD = hist_stride(plan->S);
+    b.W = plan->bp.ok ? plan->bp.W : 0;
+    b.banded = plan->bp.ok ? 1 : 0;
+    b.n_extras = plan->bp.ok ? plan->bp.n_extras : 0;
+    b.n_dense = plan->bp.ok ? plan->bp.n_dense : 0;
+    for (int k = 0; k < vit::kMaxExtras; ++k) b.extras[k] = plan->bp.extras[k];
+    b.c0 = plan->bp.c0;
+    b.have_fmax = algo == VIT_ALGO_BANDED ? 1 : 0;
+    if (const char* dbg = std::getenv("VIT_DEBUG_FLAGS")) b.debug = std::atoi(dbg);  // timing experiments only
+    b.lo_affine = plan->bp.lo_affine ? 1 : 0;
+    b.lo_off = plan->bp.lo_off;
+    for (int d = 0; d < vit::kMaxDenseRows; ++d) b.dense_rows[d] = d < plan->bp.n_dense ? plan->bp.dense_rows[d] : -1;
+    b.off_lo = plan->L.off_lo;
+    b.off_kind = plan->L.off_kind;
+    b.off_tabA = plan->L.off_tabA;
+    b.off_extraA = plan->L.off_extraA;
+    b.off_denseA = plan->L.off_denseA;
+    b.off_Arow = plan->L.off_Arow;
     hipError_t e = vit::launch_backtrace(b, (hipStream_t)stream);
     return e == hipSuccess ? VIT_OK : hip_fail(e);
 }
@@ -203,7 +241,7 @@ int vit_decode(const vit_plan* plan, const void* logE, int emis_dtype, int64_t B
     if (!states) return VIT_EINVAL;
     int rc = vit_forward(plan, logE, emis_dtype, B, T, lengths, workspace, workspace_bytes, loglik, algo, stream);
     if (rc != VIT_OK) return rc;
-    return vit_backtrace(plan, B, T, lengths, workspace, workspace_bytes, states, stream);
+    return vit_backtrace(plan, B, T, lengths, workspace, workspace_bytes, states, algo, stream);
 }
 
 int vit_voicing_map(const int32_t* states, int64_t n, int32_t n_bins, uint8_t* voiced, int32_t* bins,
@@ -214,9 +252,9 @@ int vit_voicing_map(const int32_t* states, int64_t n, int32_t n_bins, uint8_t* v
 }
 
 /* not part of the public header: DPP scan self-test used by tests/test_gpu_parity.py */
-int vit_debug_scan(const float* vals, int n_waves, int rev, float* out_v, int32_t* out_i, vit_stream stream) {
+int vit_debug_scan(const float* vals, int n_waves, int mode, float* out_v, int32_t* out_i, vit_stream stream) {
     if (!vals || !out_v || !out_i || n_waves < 1) return VIT_EINVAL;
-    hipError_t e = vit::launch_scan_selftest(vals, n_waves, rev, out_v, out_i, (hipStream_t)stream);
+    hipError_t e = vit::launch_scan_selftest(vals, n_waves, mode, out_v, out_i, (hipStream_t)stream);
     return e == hipSuccess ? VIT_OK : hip_fail(e);
 }
 

@@ -1,19 +1,21 @@
 // kernels.hip -- gfx950 (MI355X) kernels for the float32 log-domain Viterbi decoder.
 //
-// Semantics (reference: imm/tf_viterbi.py:91-107,
-// tonet/for_paper.py:1855-1868):
+// Semantics (reference: imm/tf_viterbi.py:91-107, tonet/for_paper.py:1855-1868):
 //   delta_0[j]  = fl32(log_pi[j] + logE[0][j])
 //   m_j         = max_i fl32(delta_{t-1}[i] + logA_T[j][i]);  psi_t[j] = LOWEST i attaining it
 //   delta_t[j]  = fl32(m_j + logE[t][j])
 //   s_{T-1}     = lowest argmax_j delta_{T-1}[j];  s_t = psi_{t+1}[s_{t+1}]
-// Only add / compare / select: built with -ffp-contract=off, results are bit-identical to
-// the reference's NumPy float32 loop.
+// Only add / compare / select (built with -ffp-contract=off): bit-identical to the reference's
+// NumPy float32 loop.
 //
-// Layout: one workgroup per song (dense kernel: NS songs per workgroup sharing every
-// transition tile it streams from L2), one thread per target state, delta resident in
-// LDS for the whole song, emissions read with coalesced loads one frame ahead,
-// back-pointers written as uint16 rows padded to 16 bytes.  No MFMA: the recurrence is
-// max-plus, not an add-contract.
+// "Lazy back-pointers": gfx950 retires one wave64 VALU instruction per 4 cycles per SIMD, and
+// tracking the argmax index of every (frame, state) costs more instructions than the max itself,
+// while the back-trace consumes ONE back-pointer per frame.  So
+//   * the forward kernels are value-only (packed adds + max3) and store the delta row of every
+//     frame (the reference's T1, tonet/for_paper.py:1852) instead of the back-pointer rows (T2);
+//   * the back-trace recomputes psi_{t+1}[s_{t+1}] exactly -- the same fl32 sums, first index
+//     attaining the max -- only for the state on the path.
+// No MFMA: the recurrence is max-plus, not an add-contract.
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
@@ -31,10 +33,9 @@ struct VI {
 };
 
 __device__ __forceinline__ VI vi_identity() { return VI{-INFINITY, kBig}; }
-
-// first-max: `later` (higher source index) replaces `earlier` only if strictly greater
+// first-max: `later` (higher index) replaces `earlier` only if strictly greater
 __device__ __forceinline__ VI op_fwd(VI earlier, VI later) { return later.v > earlier.v ? later : earlier; }
-// pieces visited in DESCENDING source order: the next (lower-index) piece wins ties
+// pieces visited in DESCENDING index order: the next (lower-index) piece wins ties
 __device__ __forceinline__ VI op_rev(VI acc, VI next) { return next.v >= acc.v ? next : acc; }
 
 template <int CTRL, int ROW_MASK>
@@ -46,8 +47,7 @@ __device__ __forceinline__ VI dpp_fetch(VI x) {
     return r;
 }
 
-// Inclusive wave64 scan over lanes 0..63 with the ordered first-max operator.
-// REV = false: lanes ascend in source index; REV = true: lanes DESCEND in source index.
+// Inclusive wave64 scan with the ordered first-max operator (value, index).
 // DPP: row_shr:1/2/4/8 inside each row of 16, then row_bcast:15 (rows 1,3), row_bcast:31 (rows 2,3).
 template <bool REV>
 __device__ __forceinline__ VI wave_scan(VI x) {
@@ -66,6 +66,32 @@ __device__ __forceinline__ VI wave_scan(VI x) {
     return x;
 }
 
+// ---- value-only wave primitives
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max_step(float x) {
+    // lanes without a valid source (or in a masked row) read themselves: max(x, x) = x
+    const float s = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, ROW_MASK, 0xf, false));
+    return fmaxf(x, s);
+}
+// inclusive prefix max over lanes 0..lane
+__device__ __forceinline__ float wave_scan_max(float x) {
+    x = dpp_max_step<0x111, 0xf>(x);
+    x = dpp_max_step<0x112, 0xf>(x);
+    x = dpp_max_step<0x114, 0xf>(x);
+    x = dpp_max_step<0x118, 0xf>(x);
+    x = dpp_max_step<0x142, 0xa>(x);
+    x = dpp_max_step<0x143, 0xc>(x);
+    return x;
+}
+// lane l <- x[l-1], lane 0 <- fill   (wave_shr:1)
+__device__ __forceinline__ float wave_shift_up(float x, float fill) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x138, 0xf, 0xf, false));
+}
+// max over all 64 lanes, returned in every lane (wave-uniform)
+__device__ __forceinline__ float wave_max_all(float x) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_scan_max(x)), 63));
+}
+
 template <typename ET>
 __device__ __forceinline__ float load_e(const ET* p);
 template <>
@@ -80,14 +106,14 @@ __device__ __forceinline__ int song_length(const int64_t* lengths, int song, int
     return v > T ? T : (int)v;
 }
 
-// Workgroup-wide lowest-index argmax of delta (terminal state), result to thread 0.
-__device__ __forceinline__ void terminal_argmax(float dj, int j, int S, VI* tot, int nw, int32_t* last_state,
+// Workgroup-wide lowest-index argmax of delta (terminal state); every thread of the workgroup calls.
+__device__ __forceinline__ void terminal_argmax(float dj, int j, bool valid, VI* tot, int nw, int32_t* last_state,
                                                 float* loglik, int song) {
-    VI x{j < S ? dj : -INFINITY, j < S ? j : kBig};
+    VI x{valid ? dj : -INFINITY, valid ? j : kBig};
     x = wave_scan<false>(x);
-    if ((j & 63) == 63) tot[j >> 6] = x;
+    if ((threadIdx.x & 63) == 63) tot[threadIdx.x >> 6] = x;
     __syncthreads();
-    if (j == 0) {
+    if (threadIdx.x == 0) {
         VI acc = vi_identity();
         for (int b = 0; b < nw; ++b) acc = op_fwd(acc, tot[b]);
         if (acc.i == kBig) acc.i = 0;
@@ -97,16 +123,16 @@ __device__ __forceinline__ void terminal_argmax(float dj, int j, int S, VI* tot,
 }
 
 // ---------------------------------------------------------------------------------------
-// Dense forward kernel: NS songs per workgroup; every thread owns one target state and
-// walks all S sources four at a time.  A4[q][j][0..3] = logA_T[j][4q..4q+3] is a coalesced
-// 16-byte load per lane (L2 resident, 4*S*S bytes), reused for the NS songs; the delta
-// vectors are read from LDS as wave-uniform (broadcast) 16-byte reads.
+// Dense forward kernel (any matrix): NS songs per workgroup; every thread owns one target state
+// and walks all S sources four at a time.  A4[q][j][0..3] = logA_T[j][4q..4q+3] is a coalesced
+// 16-byte load per lane (L2 resident, 4*S*S bytes per frame), reused for the NS songs; the delta
+// vectors are read from LDS as wave-uniform (broadcast) 16-byte reads.  Value-only: two packed
+// adds and two max3 per four sources.
 // ---------------------------------------------------------------------------------------
 template <int NS, typename ET>
 __global__ void __launch_bounds__(dense_max_threads(NS)) dense_forward_kernel(FwdArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int S = a.S, SP = a.SP, S4 = a.S4, T = a.T;
-    const int SD = S4 * 4;                       // delta row length in LDS (multiple of 4)
+    const int S = a.S, SP = a.SP, S4 = a.S4, T = a.T, SD = a.SD;
     float* dl = reinterpret_cast<float*>(smem);  // [2][NS][SD]
     VI* tot = reinterpret_cast<VI*>(dl + 2 * NS * SD);
 
@@ -132,7 +158,10 @@ __global__ void __launch_bounds__(dense_max_threads(NS)) dense_forward_kernel(Fw
     for (int s = 0; s < NS; ++s) {
         const size_t base = (size_t)(song0 + s) * T * S;
         float d = -INFINITY;
-        if (live[s] && j < S) d = log_pi[j] + load_e<ET>(E + base + j);
+        if (live[s] && j < S) {
+            d = log_pi[j] + load_e<ET>(E + base + j);
+            a.hist[(size_t)(song0 + s) * T * SD + j] = d;
+        }
         if (j < SD) { dl[(0 * NS + s) * SD + j] = d; dl[(1 * NS + s) * SD + j] = -INFINITY; }
         enext[s] = (live[s] && j < S && Tb[s] > 1) ? load_e<ET>(E + base + S + j) : 0.f;
     }
@@ -147,22 +176,18 @@ __global__ void __launch_bounds__(dense_max_threads(NS)) dense_forward_kernel(Fw
             if (live[s] && j < S && t + 1 < Tb[s])
                 enext[s] = load_e<ET>(E + ((size_t)(song0 + s) * T + t + 1) * S + j);
         }
-        float best[NS];
-        int arg[NS];
+        float b0[NS], b1[NS];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) { best[s] = -INFINITY; arg[s] = kBig; }
+        for (int s = 0; s < NS; ++s) { b0[s] = -INFINITY; b1[s] = -INFINITY; }
         const float* dcur = dl + cur * NS * SD;
-#pragma unroll 4
+#pragma unroll 8
         for (int q = 0; q < S4; ++q) {
             const float4 av = A4[(size_t)q * SP + j];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const float4 dv = *reinterpret_cast<const float4*>(dcur + s * SD + 4 * q);
-                float v;
-                v = dv.x + av.x; if (v > best[s]) { best[s] = v; arg[s] = 4 * q; }
-                v = dv.y + av.y; if (v > best[s]) { best[s] = v; arg[s] = 4 * q + 1; }
-                v = dv.z + av.z; if (v > best[s]) { best[s] = v; arg[s] = 4 * q + 2; }
-                v = dv.w + av.w; if (v > best[s]) { best[s] = v; arg[s] = 4 * q + 3; }
+                b0[s] = fmaxf(fmaxf(b0[s], dv.x + av.x), dv.y + av.y);
+                b1[s] = fmaxf(fmaxf(b1[s], dv.z + av.z), dv.w + av.w);
             }
         }
         float* dnxt = dl + (cur ^ 1) * NS * SD;
@@ -170,9 +195,9 @@ __global__ void __launch_bounds__(dense_max_threads(NS)) dense_forward_kernel(Fw
         for (int s = 0; s < NS; ++s) {
             if (j < S) {
                 if (live[s] && t < Tb[s]) {
-                    const int ai = arg[s] == kBig ? 0 : arg[s];
-                    dnxt[s * SD + j] = best[s] + ecur[s];
-                    a.psi[((size_t)(song0 + s) * T + t) * a.SPSI + j] = (uint16_t)ai;
+                    const float dn = fmaxf(b0[s], b1[s]) + ecur[s];
+                    dnxt[s * SD + j] = dn;
+                    a.hist[((size_t)(song0 + s) * T + t) * SD + j] = dn;
                 } else {
                     dnxt[s * SD + j] = dcur[s * SD + j];
                 }
@@ -186,71 +211,66 @@ __global__ void __launch_bounds__(dense_max_threads(NS)) dense_forward_kernel(Fw
     for (int s = 0; s < NS; ++s) {
         if (live[s]) {
             const float dj = j < S ? dl[(cur * NS + s) * SD + j] : -INFINITY;
-            terminal_argmax(dj, j, S, tot, nw, a.last_state, a.loglik, song0 + s);
+            terminal_argmax(dj, j, j < S, tot, nw, a.last_state, a.loglik, song0 + s);
         }
         __syncthreads();
     }
 }
 
 // ---------------------------------------------------------------------------------------
-// Banded forward kernel: one song per workgroup.
+// Banded forward kernel: one song per workgroup, value-only.
 //
-// Per frame, for a banded target j (window [lo_j, lo_j+W), shared constant c0, extra
-// columns X) the candidates, merged in increasing source order with strict '>':
-//   prefix  first-max_{i < lo_j, i not in X}  fl(delta_i + c0)      Pp[lo_j]
-//   window  fl(delta_i + logA_T[j][i]),  i in [lo_j, lo_j+W)        W register-resident entries
-//   suffix  first-max_{i >= lo_j+W, i not in X} fl(delta_i + c0)    Sf[lo_j+W]
-//   extras  fl(delta_x + logA_T[j][x]), x in X                      lexicographic merge
-// Dense rows (e.g. the "unvoiced" target) are reduced over all sources.
+// For a banded target j (window [lo_j, lo_j+W), shared constant c0, extra columns X):
+//   m_j = max( Pv[lo_j],                                      prefix max of fl(delta_i + c0), i < lo_j
+//              max_w fl(delta_{lo_j+w} + logA_T[j][lo_j+w]),   W register-resident window entries
+//              Sv[lo_j+W],                                     suffix max of fl(delta_i + c0), i >= lo_j+W
+//              fl(delta_x + logA_T[j][x]), x in X )
+// (extra columns are excluded from the c0 scans).  Dense rows are a full max over all sources.
+// The max of the same fl32 sums the dense recursion forms, so delta is bit-identical.
 //
-// Wave roles (NWT = target waves, 64*NWT >= S):
-//   waves 0..NWT-1  one thread per target: window candidates, merge, delta_t, back-pointer
-//   wave  NWT       prefix scan over all sources (NWT elements per lane) + dense rows 0,2
-//   wave  NWT+1     suffix scan (lanes hold the sources in descending blocks) + dense rows 1,3
-// The scan waves run beside the window phase; two workgroup barriers per frame.
+// Wave roles (NWT target waves, 64*NWT >= S):
+//   waves 0..NWT-1  one thread per target: window max, merge, delta_t, history row
+//   wave  NWT       prefix-max scan over all sources (NWT per lane)
+//   wave  NWT+1     suffix-max scan (lanes hold the sources in descending blocks)
+//   wave  NWT+2     dense rows
+// Two workgroup barriers per frame; emission rows are fetched two frames ahead.
 // ---------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ VI dpp_shift_in(VI x) {  // whole-wave shift by one lane, lane 0 gets identity
-    VI r;
-    r.v = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-INFINITY), __float_as_int(x.v), CTRL, 0xf, 0xf, false));
-    r.i = __builtin_amdgcn_update_dpp(kBig, x.i, CTRL, 0xf, 0xf, false);
-    return r;
-}
-
 template <int W, int NWT, typename ET>
-__global__ void __launch_bounds__((NWT + 2) * 64) banded_forward_kernel(FwdArgs a) {
+__global__ void __launch_bounds__((NWT + 3) * 64) banded_forward_kernel(FwdArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int NP = NWT * 64;   // padded state count handled by the target waves
-    constexpr int EPL = NWT;       // sources per lane in the scan waves
-    const int S = a.S, SP = a.SP, T = a.T;
-    float* dl = reinterpret_cast<float*>(smem);   // [NP]       delta_{t-1}; entries >= S stay -inf
-    VI* Pp = reinterpret_cast<VI*>(dl + NP);      // [NP+1]     Pp[q] = first-max over sources < q
-    VI* Sf = Pp + NP + 1;                         // [NP+1]     Sf[q] = first-max over sources >= q
-    VI* Dr = Sf + NP + 1;                         // [4]        dense-row results
-    VI* tot = Dr + kMaxDenseRows;                 // [16]       terminal argmax scratch
+    constexpr int NP = NWT * 64;
+    constexpr int EPL = NWT;
+    const int S = a.S, SP = a.SP, T = a.T, SD = a.SD;
+    float* dl = reinterpret_cast<float*>(smem);   // [NP]    delta_{t-1}; entries >= S stay -inf
+    float* Pv = dl + NP;                          // [NP+1]  Pv[q] = max_{i<q}  g_i
+    float* Sv = Pv + NP + 1;                      // [NP+1]  Sv[q] = max_{i>=q} g_i
+    float* Dv = Sv + NP + 1;                      // [4]     dense-row maxima
+    VI* tot = reinterpret_cast<VI*>(Dv + kMaxDenseRows);  // [16] terminal argmax scratch
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform for the compiler
     const int song = blockIdx.x;
     const int Tb = song_length(a.lengths, song, T);
     const ET* __restrict__ E = reinterpret_cast<const ET*>(a.logE) + (size_t)song * T * S;
-    uint16_t* __restrict__ psi = a.psi + (size_t)song * T * a.SPSI;
+    float* __restrict__ hist = a.hist + (size_t)song * T * SD;
     const float c0 = a.c0;
     const int nx = a.n_extras, nd = a.n_dense;
     const int dbg = a.debug;
-    const float* __restrict__ daT = reinterpret_cast<const float*>(a.image + a.off_denseA);
 
     // ---------------- per-role setup
     const bool is_target = wv < NWT;
-    const int j = tid;                       // target index (target waves)
+    const int j = tid;
     const bool tvalid = is_target && j < S;
-    const int jc = j < SP ? j : 0;           // clamp for image reads (image rows are SP wide)
+    const int jc = j < SP ? j : 0;
     int lo = 0, kind = -2;
     float aw[W];
     float xa[kMaxExtras];
     int xcol[kMaxExtras];
 #pragma unroll
     for (int k = 0; k < kMaxExtras; ++k) { xa[k] = -INFINITY; xcol[k] = a.extras[k]; }
+#pragma unroll
+    for (int w = 0; w < W; ++w) aw[w] = 0.f;
     if (is_target) {
         lo = reinterpret_cast<const int32_t*>(a.image + a.off_lo)[jc];
         kind = j < SP ? reinterpret_cast<const int32_t*>(a.image + a.off_kind)[jc] : -2;
@@ -260,146 +280,135 @@ __global__ void __launch_bounds__((NWT + 2) * 64) banded_forward_kernel(FwdArgs 
         for (int w = 0; w < W; ++w) aw[w] = tab[(size_t)w * SP + jc];
 #pragma unroll
         for (int k = 0; k < kMaxExtras; ++k) xa[k] = xaT[(size_t)k * SP + jc];
-    } else {
-#pragma unroll
-        for (int w = 0; w < W; ++w) aw[w] = 0.f;
     }
-    // scan waves: lane owns sources [blk*EPL, blk*EPL+EPL); the suffix wave walks blocks downwards
-    const bool is_pre = wv == NWT;
-    const int blk = is_pre ? lane : 63 - lane;
+    const int role = wv - NWT;                 // 0 prefix, 1 suffix, 2 dense rows
+    const int blk = role == 1 ? 63 - lane : lane;
     const int i0 = blk * EPL;
-    bool smask[EPL];           // source is padding or an extra column: excluded from the c0 scans
-    float dA0[EPL], dA1[EPL];  // this wave's two dense rows
+    bool smask[EPL];
+    float dA[kMaxDenseRows][EPL];
+    {
+        const float* __restrict__ daT = reinterpret_cast<const float*>(a.image + a.off_denseA);
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-        const int i = i0 + e;
-        bool m = i >= S;
+        for (int e = 0; e < EPL; ++e) {
+            const int i = i0 + e;
+            bool m = i >= S;
 #pragma unroll
-        for (int k = 0; k < kMaxExtras; ++k) m |= (k < nx && i == xcol[k]);
-        smask[e] = m;
-        const int d0 = is_pre ? 0 : 1;
-        dA0[e] = (!is_target && i < S && d0 < nd) ? daT[(size_t)d0 * SP + i] : -INFINITY;
-        dA1[e] = (!is_target && i < S && d0 + 2 < nd) ? daT[(size_t)(d0 + 2) * SP + i] : -INFINITY;
+            for (int k = 0; k < kMaxExtras; ++k) m |= (k < nx && i == xcol[k]);
+            smask[e] = m;
+#pragma unroll
+            for (int d = 0; d < kMaxDenseRows; ++d)
+                dA[d][e] = (role == 2 && i < S && d < nd) ? daT[(size_t)d * SP + i] : -INFINITY;
+        }
     }
 
     // ---------------- frame 0
     if (is_target) {
         float d = -INFINITY;
-        if (tvalid) d = reinterpret_cast<const float*>(a.image + a.off_logpi)[j] + load_e<ET>(E + j);
+        if (tvalid) {
+            d = reinterpret_cast<const float*>(a.image + a.off_logpi)[j] + load_e<ET>(E + j);
+            hist[j] = d;
+        }
         dl[j] = d;
     } else if (lane == 0) {
-        if (is_pre) Pp[0] = vi_identity(); else Sf[NP] = vi_identity();
+        if (role == 0) Pv[0] = -INFINITY;
+        if (role == 1) Sv[NP] = -INFINITY;
     }
     // Emission rows are fetched two frames ahead and consumed only at the end of a frame: vmcnt
-    // retires in order, so a wait on a younger load would also wait for the previous frame's
-    // back-pointer store.
+    // retires in order, so a wait on a younger load would also wait for the previous frame's store.
     float e_a = (tvalid && Tb > 1) ? load_e<ET>(E + S + j) : 0.f;
     float e_b = (tvalid && Tb > 2) ? load_e<ET>(E + 2 * (size_t)S + j) : 0.f;
-    // Retire every set-up load here, so that inside the frame loop the only vector-memory
-    // operations the wait-count pass has to reason about are the two it issues per frame.
+    // Retire every set-up load here so the frame loop only sees the two memory ops it issues.
 #pragma unroll
     for (int w = 0; w < W; ++w) asm volatile("" ::"v"(aw[w]));
 #pragma unroll
     for (int k = 0; k < kMaxExtras; ++k) asm volatile("" ::"v"(xa[k]));
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) asm volatile("" ::"v"(dA0[e]), "v"(dA1[e]));
+    for (int e = 0; e < EPL; ++e) {
+#pragma unroll
+        for (int d = 0; d < kMaxDenseRows; ++d) asm volatile("" ::"v"(dA[d][e]));
+    }
     asm volatile("" ::"v"(lo), "v"(kind), "v"(e_a), "v"(e_b));
     __syncthreads();
 
     auto frame = [&](const int t, float& e_slot) {
-        float best = -INFINITY;
-        int arg = kBig;
-        float xv[kMaxExtras];
-#pragma unroll
-        for (int k = 0; k < kMaxExtras; ++k) xv[k] = -INFINITY;
-
+        float m = -INFINITY;
         if (is_target) {
-            // ---- window candidates (everything here reads delta_{t-1})
+            // ---- window max (reads delta_{t-1}); four independent max3 chains
+            float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
 #pragma unroll
             for (int k = 0; k < kMaxExtras; ++k)
-                if (k < nx) xv[k] = dl[xcol[k]] + xa[k];
+                if (k < nx) m0 = fmaxf(m0, dl[xcol[k]] + xa[k]);
             if (!(dbg & 1)) {
 #pragma unroll
-                for (int w = 0; w < W; ++w) {
-                    const float v = dl[lo + w] + aw[w];
-                    if (v > best) { best = v; arg = w; }
+                for (int w = 0; w + 7 < W; w += 8) {
+                    m0 = fmaxf(fmaxf(m0, dl[lo + w + 0] + aw[w + 0]), dl[lo + w + 1] + aw[w + 1]);
+                    m1 = fmaxf(fmaxf(m1, dl[lo + w + 2] + aw[w + 2]), dl[lo + w + 3] + aw[w + 3]);
+                    m2 = fmaxf(fmaxf(m2, dl[lo + w + 4] + aw[w + 4]), dl[lo + w + 5] + aw[w + 5]);
+                    m3 = fmaxf(fmaxf(m3, dl[lo + w + 6] + aw[w + 6]), dl[lo + w + 7] + aw[w + 7]);
                 }
             }
+            m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
         } else if (!(dbg & 2)) {
             float d[EPL];
 #pragma unroll
             for (int e = 0; e < EPL; ++e) d[e] = dl[i0 + e];
-            VI p[EPL];
-            if (is_pre) {
-                // inclusive first-max prefix over this lane's sources, ascending
-                VI run = vi_identity();
+            if (role == 0) {
+                float p[EPL];
+                float run = -INFINITY;
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
-                    const VI x{smask[e] ? -INFINITY : d[e] + c0, smask[e] ? kBig : i0 + e};
-                    run = op_fwd(run, x);
+                    run = fmaxf(run, smask[e] ? -INFINITY : d[e] + c0);
                     p[e] = run;
                 }
-                const VI ex = dpp_shift_in<0x138>(wave_scan<false>(run));  // sources of all lower lanes
+                const float inc = wave_scan_max(run);
+                const float ex = wave_shift_up(inc, -INFINITY);                 // sources of all lower lanes
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) Pp[i0 + e + 1] = op_fwd(ex, p[e]);
-            } else {
-                // inclusive first-max suffix over this lane's sources, descending
-                VI run = vi_identity();
+                for (int e = 0; e < EPL; ++e) Pv[i0 + e + 1] = fmaxf(ex, p[e]);
+                // floor maximum over delta_{t-1}: lets the back-trace skip the floor candidates
+                if (lane == 63 && !(dbg & 8)) a.fmax[(size_t)song * T + (t - 1)] = inc;
+            } else if (role == 1) {
+                float p[EPL];
+                float run = -INFINITY;
 #pragma unroll
                 for (int e = EPL - 1; e >= 0; --e) {
-                    const VI x{smask[e] ? -INFINITY : d[e] + c0, smask[e] ? kBig : i0 + e};
-                    run = op_rev(run, x);
+                    run = fmaxf(run, smask[e] ? -INFINITY : d[e] + c0);
                     p[e] = run;
                 }
-                const VI ex = dpp_shift_in<0x138>(wave_scan<true>(run));   // sources of all higher blocks
+                const float ex = wave_shift_up(wave_scan_max(run), -INFINITY);  // sources of all higher blocks
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) Sf[i0 + e] = op_rev(ex, p[e]);
-            }
-            // dense rows: full first-max over every source
+                for (int e = 0; e < EPL; ++e) Sv[i0 + e] = fmaxf(ex, p[e]);
+            } else {
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int dr = (is_pre ? 0 : 1) + 2 * r;
-                if (dr < nd) {
-                    VI run = vi_identity();
-                    if (is_pre) {
+                for (int dr = 0; dr < kMaxDenseRows; ++dr) {
+                    if (dr < nd) {
+                        float run = -INFINITY;
 #pragma unroll
-                        for (int e = 0; e < EPL; ++e)
-                            run = op_fwd(run, VI{d[e] + (r ? dA1[e] : dA0[e]), i0 + e < S ? i0 + e : kBig});
-                        run = wave_scan<false>(run);
-                    } else {
-#pragma unroll
-                        for (int e = EPL - 1; e >= 0; --e)
-                            run = op_rev(run, VI{d[e] + (r ? dA1[e] : dA0[e]), i0 + e < S ? i0 + e : kBig});
-                        run = wave_scan<true>(run);
+                        for (int e = 0; e < EPL; ++e) run = fmaxf(run, d[e] + dA[dr][e]);
+                        run = wave_max_all(run);
+                        if (lane == 0) Dv[dr] = run;
                     }
-                    if (lane == 63) Dr[dr] = run;
                 }
             }
         }
         __syncthreads();
 
         if (is_target && !(dbg & 4)) {
-            // ---- merge in increasing source order, write delta_t and the back-pointer
-            VI acc = Pp[lo];
-            acc = op_fwd(acc, VI{best, arg == kBig ? kBig : lo + arg});
-            acc = op_fwd(acc, Sf[lo + W]);
-#pragma unroll
-            for (int k = 0; k < kMaxExtras; ++k)
-                if (k < nx && (xv[k] > acc.v || (xv[k] == acc.v && xcol[k] < acc.i && acc.i != kBig)))
-                    acc = VI{xv[k], xcol[k]};  // acc.i == kBig <=> everything so far is -inf: stays "none" -> 0
-            const VI dres = Dr[kind >= 0 ? kind : 0];
-            if (kind >= 0) acc = dres;
+            m = fmaxf(fmaxf(m, Pv[lo]), Sv[lo + W]);
+            const float dres = Dv[kind >= 0 ? kind : 0];
+            if (kind >= 0) m = dres;
             if (tvalid) {
-                if (acc.i == kBig) acc.i = 0;
-                dl[j] = acc.v + e_slot;
+                const float dn = m + e_slot;
+                dl[j] = dn;
                 if (!(dbg & 8)) {
-                    psi[(size_t)t * a.SPSI + j] = (uint16_t)acc.i;
+                    hist[(size_t)t * SD + j] = dn;
                     if (t + 2 < Tb) e_slot = load_e<ET>(E + (size_t)(t + 2) * S + j);
                 }
             }
         }
         __syncthreads();
     };
+    const unsigned long long clk0 = (dbg & 48) ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long rt0 = (dbg & 48) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     int t = 1;
     for (; t + 1 < Tb; t += 2) {
         frame(t, e_a);
@@ -407,76 +416,296 @@ __global__ void __launch_bounds__((NWT + 2) * 64) banded_forward_kernel(FwdArgs 
     }
     if (t < Tb) frame(t, e_a);
 
-    terminal_argmax(is_target ? dl[j] : -INFINITY, tid, S, tot, NWT + 2, a.last_state, a.loglik, song);
-}
-
-// ---------------------------------------------------------------------------------------
-// Back-trace: one workgroup per song.  Tiles of K consecutive back-pointer rows are staged
-// through LDS with coalesced 16-byte loads (the next tile is fetched into registers while
-// lane 0 chases the current one), the chase itself runs on LDS latency, and the decoded
-// states of a tile are written back coalesced.
-// ---------------------------------------------------------------------------------------
-constexpr int kBtThreads = 256;
-constexpr int kBtMaxVec = 12;  // 16-byte vectors per thread per tile -> tile <= 48 KiB
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void bt_fetch(u32x4 (&stage)[kBtMaxVec], const u32x4* __restrict__ psi, int top, int K,
-                                         int rowv, int tid) {
-    const int first = top - K + 1 > 1 ? top - K + 1 : 1;  // first row of the tile
-    const int nvec = (top - first + 1) * rowv;
-#pragma unroll
-    for (int v = 0; v < kBtMaxVec; ++v) {
-        const int idx = tid + v * kBtThreads;
-        stage[v] = psi[(size_t)first * rowv + (idx < nvec ? idx : nvec - 1)];  // clamped: always in the tile
+    terminal_argmax(is_target ? dl[j] : -INFINITY, j, tvalid, tot, NWT + 3, a.last_state, a.loglik, song);
+    if ((dbg & 48) && tid == 0 && a.loglik) {  // timing experiments only: cycles (16) or 100 MHz ticks (32) per frame
+        const unsigned long long d = (dbg & 16) ? __builtin_amdgcn_s_memtime() - clk0 : __builtin_amdgcn_s_memrealtime() - rt0;
+        a.loglik[song] = (float)d / (float)(Tb > 1 ? Tb - 1 : 1);
     }
 }
 
-__global__ void __launch_bounds__(kBtThreads) backtrace_kernel(BtArgs a) {
+// ---------------------------------------------------------------------------------------
+// Lazy back-trace: one wave per song (kBtWaves songs per workgroup share the LDS tables).
+// For frame t (descending) and the path state j at t+1 it rebuilds the candidates of target j
+//   fl(delta_t[i] + logA_T[j][i])   for every source i
+// from the stored delta row (window / c0 floor / extra columns / dense row, or the full matrix
+// row for unstructured matrices), takes the max over the wave and picks the LOWEST index
+// attaining it (v_cmp_eq lane masks + s_ff1).  Delta rows are staged through LDS in tiles of K
+// frames; the next tile is in flight in registers while the current one is chased.
+// ---------------------------------------------------------------------------------------
+constexpr int kBtWaves = 4;
+constexpr int kBtVec = 12;  // float4 per lane per tile: K * SD <= 12 * 256 floats
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void bt_fetch(f32x4 (&stage)[kBtVec], const f32x4* __restrict__ rows, int nvec, int lane) {
+#pragma unroll
+    for (int v = 0; v < kBtVec; ++v) {
+        const int idx = lane + v * 64;
+        stage[v] = rows[idx < nvec ? idx : nvec - 1];  // clamped: always inside the tile
+    }
+}
+
+// MODE 0: speculative pass, one wave per (song, chunk).  MODE 1: verify pass, one wave per song.
+template <int NWT, int MODE>
+__global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int K = a.K;
-    const int rowv = a.SPSI / 8;                       // u32x4 per row
-    u32x4* tile = reinterpret_cast<u32x4*>(smem);      // [kBtMaxVec*kBtThreads] (K*rowv of it used)
-    int32_t* out = reinterpret_cast<int32_t*>(tile + kBtMaxVec * kBtThreads);  // [K]
-    int32_t& s_cur = out[K];                                             // chase cursor (lane 0 only)
+    constexpr int EPL = NWT;               // sources per lane, strided: i = e*64 + lane
+    const int S = a.S, SP = a.SP, SD = a.SD, T = a.T, W = a.W, K = a.K;
+    const bool banded = a.banded != 0;
+    const int nx = a.n_extras, nd = a.n_dense;
+    const int WX = W + nx;                  // window candidates + extra-column candidates, one per lane
+    const bool fast_ok = banded && a.have_fmax && WX <= 64;
+    // LDS: [tile per wave: kBtVec*64 float4][out per wave: 64 ints][fmax per wave: 64 floats]
+    //      [tables: lo, kind, tabX = window rows then extra rows]
+    f32x4* tiles = reinterpret_cast<f32x4*>(smem);
+    int32_t* outs = reinterpret_cast<int32_t*>(tiles + kBtWaves * kBtVec * 64);
+    float* fms = reinterpret_cast<float*>(outs + kBtWaves * 64);
+    int32_t* loL = reinterpret_cast<int32_t*>(fms + kBtWaves * 64);
+    int32_t* kindL = loL + SP;
+    float* tabX = reinterpret_cast<float*>(kindL + SP);   // [(W + kMaxExtras)][SP]
 
-    const int song = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int T = a.T;
-    const int Tb = song_length(a.lengths, song, T);
-    const u32x4* __restrict__ psi = reinterpret_cast<const u32x4*>(a.psi + (size_t)song * T * a.SPSI);
-    int32_t* __restrict__ states = a.states + (size_t)song * T;
-
-    for (int t = Tb + tid; t < T; t += kBtThreads) states[t] = -1;
-    if (tid == 0) {
-        s_cur = a.last_state[song];
-        states[Tb - 1] = s_cur;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform for the compiler
+    if (banded) {
+        const int32_t* gl = reinterpret_cast<const int32_t*>(a.image + a.off_lo);
+        const int32_t* gk = reinterpret_cast<const int32_t*>(a.image + a.off_kind);
+        const float* gx = reinterpret_cast<const float*>(a.image + a.off_extraA);
+        const float* gt = reinterpret_cast<const float*>(a.image + a.off_tabA);
+        for (int k = tid; k < SP; k += kBtWaves * 64) { loL[k] = gl[k]; kindL[k] = gk[k]; }
+        for (int k = tid; k < W * SP; k += kBtWaves * 64) tabX[k] = gt[k];
+        for (int k = tid; k < kMaxExtras * SP; k += kBtWaves * 64) tabX[W * SP + k] = gx[k];
     }
+    __syncthreads();
 
-    // rows t in [1, Tb-1] are consumed from the top; tile covers rows (hi-K, hi]
-    u32x4 stage[kBtMaxVec];
-    int hi = Tb - 1;
-    if (hi >= 1) bt_fetch(stage, psi, hi, K, rowv, tid);
-    while (hi >= 1) {
-        const int first = hi - K + 1 > 1 ? hi - K + 1 : 1;
-        const int rows = hi - first + 1;
-        __syncthreads();  // previous tile fully consumed
+    const int C = a.chunks;
+    const int gw = blockIdx.x * kBtWaves + wv;          // global wave index
+    const int song = MODE == 0 ? gw / C : gw;
+    const int chunk = MODE == 0 ? gw % C : 0;
+    if (song >= a.B) return;
+    const int Tb = song_length(a.lengths, song, T);
+    int32_t* __restrict__ states = a.states + (size_t)song * T;
+    const float* __restrict__ hist = a.hist + (size_t)song * T * SD;
+    const float* __restrict__ fmaxg = a.fmax + (size_t)song * T;
+    const float* __restrict__ Arow = reinterpret_cast<const float*>(a.image + a.off_Arow);
+    const float c0 = a.c0;
+    float* tile = reinterpret_cast<float*>(tiles + wv * kBtVec * 64);
+    int32_t* out = outs + wv * 64;
+    float* fm = fms + wv * 64;
+
+
+    // loop invariants
+    float dA[kMaxDenseRows][EPL];
+    bool isx[EPL];                          // source excluded from the c0 floor: extra column or padding
+    {
+        const float* __restrict__ daT = reinterpret_cast<const float*>(a.image + a.off_denseA);
 #pragma unroll
-        for (int v = 0; v < kBtMaxVec; ++v) tile[tid + v * kBtThreads] = stage[v];  // slots >= nvec hold clamped copies
-        __syncthreads();
-        const int next_hi = first - 1;
-        if (next_hi >= 1) bt_fetch(stage, psi, next_hi, K, rowv, tid);
-        if (tid == 0) {
-            const uint16_t* rowsp = reinterpret_cast<const uint16_t*>(tile);
-            int cur = s_cur;
-            for (int r = rows - 1; r >= 0; --r) {
-                cur = rowsp[(size_t)r * a.SPSI + cur];
-                out[r] = cur;                 // state at frame first + r - 1
-            }
-            s_cur = cur;
+        for (int e = 0; e < EPL; ++e) {
+            const int i = e * 64 + lane;
+            bool x = i >= S;
+#pragma unroll
+            for (int k = 0; k < kMaxExtras; ++k) x |= (k < nx && i == a.extras[k]);
+            isx[e] = x;
+#pragma unroll
+            for (int d = 0; d < kMaxDenseRows; ++d)
+                dA[d][e] = (banded && d < nd && i < S) ? daT[(size_t)d * SP + i] : -INFINITY;
         }
-        __syncthreads();
-        for (int r = tid; r < rows; r += kBtThreads) states[first + r - 1] = out[r];
-        hi = next_hi;
+    }
+    // fast path: lane l < W evaluates window source lo + l, lane W + k evaluates extra column k
+    const int xsrc = (lane >= W && lane < WX) ? a.extras[(lane - W) & (kMaxExtras - 1)] : 0;
+    const unsigned long long wmask = W >= 64 ? ~0ull : ((1ull << W) - 1ull);
+
+    // chase(top, bottom, cur, write): decide the states of frames top .. bottom (descending) from the
+    // delta rows top .. bottom, starting from state `cur` at frame top+1; a tile holds rows [first, top].
+    const int rv = SD / 4;  // float4 per row
+    auto chase = [&](int top, const int bottom, int cur, const bool write) -> int {
+    f32x4 stage[kBtVec];
+    float fstage = 0.f;
+    if (top >= bottom) {
+        const int first = top - K + 1 > bottom ? top - K + 1 : bottom;
+        bt_fetch(stage, reinterpret_cast<const f32x4*>(hist + (size_t)first * SD), (top - first + 1) * rv, lane);
+        if (fast_ok) fstage = fmaxg[first + (lane < top - first + 1 ? lane : 0)];
+    }
+    while (top >= bottom) {
+        const int first = top - K + 1 > bottom ? top - K + 1 : bottom;
+        const int rows = top - first + 1;
+#pragma unroll
+        for (int v = 0; v < kBtVec; ++v) reinterpret_cast<f32x4*>(tile)[lane + v * 64] = stage[v];
+        fm[lane] = fstage;
+        const int ntop = first - 1;
+        if (ntop >= bottom) {
+            const int nfirst = ntop - K + 1 > bottom ? ntop - K + 1 : bottom;
+            bt_fetch(stage, reinterpret_cast<const f32x4*>(hist + (size_t)nfirst * SD), (ntop - nfirst + 1) * rv, lane);
+            if (fast_ok) fstage = fmaxg[nfirst + (lane < ntop - nfirst + 1 ? lane : 0)];
+        }
+        for (int r = rows - 1; r >= 0; --r) {
+            const float* row = tile + r * SD;   // delta_t, t = first + r; decides the state at frame t
+            const int jj = __builtin_amdgcn_readfirstlane(cur);  // path state at frame t+1 (wave-uniform)
+            int lo = 0;
+            int kd = -3;                         // -3 unstructured plan, -1 banded row, >= 0 dense row
+            if (banded) {
+                if (a.lo_affine) {
+                    lo = jj - a.lo_off;
+                    lo = lo < 0 ? 0 : (lo > S - W ? S - W : lo);
+                    kd = -1;
+#pragma unroll
+                    for (int d = 0; d < kMaxDenseRows; ++d) kd = (d < nd && jj == a.dense_rows[d]) ? d : kd;
+                } else {
+                    kd = __builtin_amdgcn_readfirstlane(kindL[jj]);
+                    lo = __builtin_amdgcn_readfirstlane(loL[jj]);
+                }
+            }
+            bool done = false;
+            if (fast_ok && (kd == -1 || (a.debug & 64))) {
+                // ---- common case: only the window + extra-column candidates of target jj
+                const int src = lane < W ? lo + lane : xsrc;
+                float v = -INFINITY;
+                if (lane < WX) v = row[src] + tabX[lane * SP + jj];
+                const float m = wave_max_all(v);
+                const float mf = fm[r];          // max_i fl(delta_t[i] + c0): bound on every floor candidate
+                if (mf < m || (a.debug & 64)) {  // no floor candidate can tie or win
+                    const unsigned long long mk = __ballot(v == m);
+                    unsigned idx = 0x7fffffffu;
+                    if (mk & wmask) idx = lo + __builtin_ctzll(mk & wmask);
+                    unsigned long long mx = W >= 64 ? 0ull : (mk >> W);
+                    while (mx) {
+                        const unsigned c = a.extras[__builtin_ctzll(mx) & (kMaxExtras - 1)];
+                        idx = c < idx ? c : idx;
+                        mx &= mx - 1;
+                    }
+                    cur = (int)idx;
+                    done = true;
+                }
+            }
+            if (!done && !(a.debug & 128)) {
+                // ---- full evaluation: every source (c0 floor / window / extras / dense row / matrix row)
+                float d[EPL], vf[EPL];
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    const int i = e * 64 + lane;
+                    d[e] = i < S ? row[i] : -INFINITY;
+                }
+                float vw = -INFINITY;
+                if (kd == -1) {
+                    const int src = lane < W ? lo + lane : xsrc;
+                    if (lane < WX) vw = row[src] + tabX[lane * SP + jj];
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) {
+                        const int i = e * 64 + lane;
+                        const bool excl = isx[e] || (unsigned)(i - lo) < (unsigned)W;
+                        vf[e] = excl ? -INFINITY : d[e] + c0;
+                    }
+                    if (WX > 64) {  // extras did not fit beside the window: fold them into the strided part
+#pragma unroll
+                        for (int e = 0; e < EPL; ++e) {
+                            const int i = e * 64 + lane;
+#pragma unroll
+                            for (int k = 0; k < kMaxExtras; ++k)
+                                if (k < nx && i == a.extras[k]) vf[e] = d[e] + tabX[(W + k) * SP + jj];
+                        }
+                    }
+                } else if (kd >= 0) {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) {
+                        float av = dA[0][e];
+#pragma unroll
+                        for (int q = 1; q < kMaxDenseRows; ++q) av = kd == q ? dA[q][e] : av;
+                        vf[e] = d[e] + av;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) {
+                        const int i = e * 64 + lane;
+                        vf[e] = i < S ? d[e] + Arow[(size_t)jj * SP + i] : -INFINITY;
+                    }
+                }
+                float m = vw;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) m = fmaxf(m, vf[e]);
+                m = wave_max_all(m);
+                // lowest index among the candidates equal to the max (an all -inf frame resolves to
+                // index 0 like np.argmax: every in-range source then matches)
+                unsigned idx = 0x7fffffffu;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    const unsigned long long mk = __ballot(vf[e] == m && e * 64 + lane < S);
+                    if (mk) { const unsigned c = e * 64 + __builtin_ctzll(mk); idx = c < idx ? c : idx; }
+                }
+                if (kd == -1) {
+                    const unsigned long long mk = __ballot(vw == m && lane < WX);
+                    if (mk & wmask) { const unsigned c = lo + __builtin_ctzll(mk & wmask); idx = c < idx ? c : idx; }
+                    unsigned long long mx = (W >= 64 || WX > 64) ? 0ull : (mk >> W);
+                    while (mx) {
+                        const unsigned c = a.extras[__builtin_ctzll(mx) & (kMaxExtras - 1)];
+                        idx = c < idx ? c : idx;
+                        mx &= mx - 1;
+                    }
+                }
+                cur = idx == 0x7fffffffu ? 0 : (int)idx;
+            }
+            if (lane == 0) out[r] = cur;
+        }
+        if (write)
+            for (int r = lane; r < rows; r += 64) states[first + r] = out[r];
+        top = ntop;
+    }
+    return cur;
+    };
+
+    // Frames 0 .. Tb-2 are decided (frame Tb-1 is the terminal state).  They are split into C chunks
+    // [lo_c, hi_c); chunk c is chased from a warm-up point `a.warm` frames above hi_c, starting from
+    // the best state of that frame (a guess); survivor paths coalesce, and MODE 1 verifies that the
+    // state chunk c reached at frame hi_c equals what chunk c+1 (already verified) decided there --
+    // if not, the chunk is chased again from the true state.  The result is exact either way.
+    const int L = Tb - 1;
+    if (MODE == 0) {
+        const int lo_c = (int)((long long)L * chunk / C), hi_c = (int)((long long)L * (chunk + 1) / C);
+        if (chunk == C - 1) {
+            for (int t = Tb + lane; t < T; t += 64) states[t] = -1;
+            if (lane == 0) states[Tb - 1] = a.last_state[song];
+        }
+        int top = hi_c - 1 + a.warm;
+        int cur;
+        if (chunk == C - 1 || top >= L - 1) {
+            top = L - 1;
+            cur = __builtin_amdgcn_readfirstlane(a.last_state[song]);
+        } else {
+            // guess: lowest-index argmax of delta row top+1
+            const float* g = hist + (size_t)(top + 1) * SD;
+            float d[EPL];
+            float m = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int i = e * 64 + lane;
+                d[e] = i < S ? g[i] : -INFINITY;
+                m = fmaxf(m, d[e]);
+            }
+            m = wave_max_all(m);
+            unsigned idx = 0x7fffffffu;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const unsigned long long mk = __ballot(d[e] == m && e * 64 + lane < S);
+                if (mk) { const unsigned c = e * 64 + __builtin_ctzll(mk); idx = c < idx ? c : idx; }
+            }
+            cur = idx == 0x7fffffffu ? 0 : (int)idx;
+        }
+        if (hi_c <= lo_c) {                       // empty chunk (very short song)
+            if (lane == 0) a.entry[(size_t)song * C + chunk] = cur;
+            return;
+        }
+        cur = chase(top, hi_c, cur, false);       // warm-up: frames top .. hi_c, nothing written
+        if (lane == 0) a.entry[(size_t)song * C + chunk] = cur;   // state this chunk assumed at frame hi_c
+        chase(hi_c - 1, lo_c, cur, true);
+    } else {
+        int truth = -1;                           // verified state at frame hi_c of the chunk being checked
+        for (int c = C - 2; c >= 0; --c) {
+            const int lo_c = (int)((long long)L * c / C), hi_c = (int)((long long)L * (c + 1) / C);
+            if (truth < 0) truth = __builtin_amdgcn_readfirstlane(states[hi_c]);
+            const int assumed = __builtin_amdgcn_readfirstlane(a.entry[(size_t)song * C + c]);
+            if (hi_c > lo_c && assumed != truth) {
+                truth = chase(hi_c - 1, lo_c, truth, true);   // re-chase from the true state; ends at frame lo_c
+            } else {
+                truth = -1;                       // chunk c stands: its frame lo_c is already in `states`
+            }
+        }
     }
 }
 
@@ -490,12 +719,17 @@ __global__ void voicing_map_kernel(const int32_t* __restrict__ states, int64_t n
     }
 }
 
-// DPP scan self-test: out[lane] = inclusive first-max scan of (vals[lane], lane) per 64 lanes.
-__global__ void scan_selftest_kernel(const float* __restrict__ vals, int rev, float* __restrict__ out_v,
+// DPP self-test: mode 0/1 = (value, index) first-max scan fwd/rev; mode 2 = value-only prefix max;
+// mode 3 = wave_shift_up of the prefix max; mode 4 = wave_max_all.
+__global__ void scan_selftest_kernel(const float* __restrict__ vals, int mode, float* __restrict__ out_v,
                                      int32_t* __restrict__ out_i) {
     const int j = threadIdx.x + blockIdx.x * blockDim.x;
     VI x{vals[j], (int)threadIdx.x};
-    x = rev ? wave_scan<true>(x) : wave_scan<false>(x);
+    if (mode == 0) x = wave_scan<false>(x);
+    else if (mode == 1) x = wave_scan<true>(x);
+    else if (mode == 2) x.v = wave_scan_max(x.v);
+    else if (mode == 3) x.v = wave_shift_up(wave_scan_max(x.v), -INFINITY);
+    else x.v = wave_max_all(x.v);
     out_v[j] = x.v;
     out_i[j] = x.i;
 }
@@ -505,8 +739,7 @@ __global__ void scan_selftest_kernel(const float* __restrict__ vals, int rev, fl
 // ---------------------------------------------------------------------------------------
 template <int NS, typename ET>
 static hipError_t launch_dense_t(const FwdArgs& a, hipStream_t st) {
-    const int SD = a.S4 * 4;
-    const size_t lds = sizeof(float) * 2 * NS * SD + sizeof(VI) * 16;
+    const size_t lds = sizeof(float) * 2 * NS * a.SD + sizeof(VI) * 16;
     const int grid = (int)((a.B + NS - 1) / NS);
     hipLaunchKernelGGL((dense_forward_kernel<NS, ET>), dim3(grid), dim3(a.SP), lds, st, a);
     return hipGetLastError();
@@ -527,8 +760,8 @@ hipError_t launch_dense(const FwdArgs& a, int ns, bool f16, hipStream_t st) {
 template <int W, int NWT, typename ET>
 static hipError_t launch_banded_t(const FwdArgs& a, hipStream_t st) {
     constexpr int NP = NWT * 64;
-    const size_t lds = sizeof(float) * NP + sizeof(VI) * (2 * (NP + 1) + kMaxDenseRows + 16);
-    hipLaunchKernelGGL((banded_forward_kernel<W, NWT, ET>), dim3((int)a.B), dim3((NWT + 2) * 64), lds, st, a);
+    const size_t lds = sizeof(float) * (NP + 2 * (NP + 1) + kMaxDenseRows) + sizeof(VI) * 16;
+    hipLaunchKernelGGL((banded_forward_kernel<W, NWT, ET>), dim3((int)a.B), dim3((NWT + 3) * 64), lds, st, a);
     return hipGetLastError();
 }
 
@@ -568,16 +801,43 @@ hipError_t launch_banded(const FwdArgs& a, bool f16, hipStream_t st) {
     return f16 ? launch_banded_e<__half>(a, st) : launch_banded_e<float>(a, st);
 }
 
-int backtrace_tile_rows(int SPSI) {
-    int k = (kBtMaxVec * kBtThreads * 16) / (SPSI * 2);
-    return k > 128 ? 128 : (k < 1 ? 1 : k);
+int backtrace_tile_rows(int SD) {
+    int k = (kBtVec * 256) / SD;
+    return k > 64 ? 64 : (k < 1 ? 1 : k);
+}
+
+template <int NWT>
+static hipError_t launch_bt_t(const BtArgs& a, hipStream_t st) {
+    size_t lds = sizeof(f32x4) * kBtWaves * kBtVec * 64 + sizeof(int32_t) * kBtWaves * 64 * 2;
+    if (a.banded) lds += sizeof(int32_t) * 2 * a.SP + sizeof(float) * (kMaxExtras + a.W) * a.SP;
+    const long long waves0 = (long long)a.B * a.chunks;
+    hipLaunchKernelGGL((lazy_backtrace_kernel<NWT, 0>), dim3((int)((waves0 + kBtWaves - 1) / kBtWaves)), dim3(kBtWaves * 64),
+                       lds, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || a.chunks <= 1) return e;
+    hipLaunchKernelGGL((lazy_backtrace_kernel<NWT, 1>), dim3((int)((a.B + kBtWaves - 1) / kBtWaves)), dim3(kBtWaves * 64),
+                       lds, st, a);
+    return hipGetLastError();
+}
+
+int backtrace_chunks(int64_t B, int T) {
+    // enough (song, chunk) waves to cover the chip twice over, chunks no shorter than ~8 warm-ups
+    long long c = (2 * 1024 + B - 1) / (B > 0 ? B : 1);
+    const long long cmax = T / (8 * kBtWarm) > 1 ? T / (8 * kBtWarm) : 1;
+    c = c > cmax ? cmax : c;
+    c = c > kBtMaxChunks ? kBtMaxChunks : c;
+    return c < 1 ? 1 : (int)c;
 }
 
 hipError_t launch_backtrace(BtArgs a, hipStream_t st) {
-    a.K = backtrace_tile_rows(a.SPSI);
-    const size_t lds = (size_t)kBtMaxVec * kBtThreads * 16 + sizeof(int32_t) * (a.K + 1);
-    hipLaunchKernelGGL(backtrace_kernel, dim3((int)a.B), dim3(kBtThreads), lds, st, a);
-    return hipGetLastError();
+    a.K = backtrace_tile_rows(a.SD);
+    const int nwt = (a.S + 63) / 64;
+    if (nwt <= 2) return launch_bt_t<2>(a, st);
+    if (nwt <= 4) return launch_bt_t<4>(a, st);
+    if (nwt <= 6) return launch_bt_t<6>(a, st);
+    if (nwt <= 8) return launch_bt_t<8>(a, st);
+    if (nwt <= 12) return launch_bt_t<12>(a, st);
+    return launch_bt_t<16>(a, st);
 }
 
 hipError_t launch_voicing_map(const int32_t* states, int64_t n, int32_t n_bins, uint8_t* voiced, int32_t* bins,
@@ -589,9 +849,9 @@ hipError_t launch_voicing_map(const int32_t* states, int64_t n, int32_t n_bins, 
     return hipGetLastError();
 }
 
-hipError_t launch_scan_selftest(const float* vals, int n_waves, int rev, float* out_v, int32_t* out_i,
+hipError_t launch_scan_selftest(const float* vals, int n_waves, int mode, float* out_v, int32_t* out_i,
                                 hipStream_t st) {
-    hipLaunchKernelGGL(scan_selftest_kernel, dim3(n_waves), dim3(64), 0, st, vals, rev, out_v, out_i);
+    hipLaunchKernelGGL(scan_selftest_kernel, dim3(n_waves), dim3(64), 0, st, vals, mode, out_v, out_i);
     return hipGetLastError();
 }
 

@@ -26,11 +26,12 @@ struct FwdArgs {
     const uint8_t* image;   // device plan image
     const void* logE;       // [B,T,S] f32 or f16
     const int64_t* lengths; // [B] or null
-    uint16_t* psi;          // [B,T,SPSI]
+    float* hist;            // [B,T,SD] delta history (the reference's T1), SD = ceil(S/4)*4
+    float* fmax;            // [B,T] banded plan: fmax[t] = max_i fl(delta_t[i] + c0) over non-extra sources
     int32_t* last_state;    // [B]
     float* loglik;          // [B] or null
     int64_t B;
-    int T, S, SP, S4, SPSI, W;
+    int T, S, SP, S4, SD, W;
     int n_extras, n_dense;
     int extras[kMaxExtras];
     float c0;
@@ -39,12 +40,25 @@ struct FwdArgs {
 };
 
 struct BtArgs {
-    const uint16_t* psi;
+    const uint8_t* image;
+    const float* hist;      // [B,T,SD]
+    const float* fmax;      // [B,T] (banded plan)
     const int32_t* last_state;
     const int64_t* lengths;
     int32_t* states;        // [B,T]
+    int32_t* entry;         // [B,chunks] state each chunk assumed at its upper boundary
     int64_t B;
-    int T, SPSI, K;
+    int T, S, SP, SD, W, K;
+    int chunks, warm;       // time-parallel back-trace: chunks per song, warm-up frames
+    int banded;             // 1: row structure (window / c0 / extras / dense rows) proven by the plan
+    int have_fmax;          // the forward pass was the banded kernel (it fills fmax)
+    int debug;              // timing-only ablation mask (VIT_DEBUG_FLAGS); 0 in production
+    int lo_affine, lo_off;  // lo[j] == clamp(j - lo_off, 0, S - W)
+    int dense_rows[kMaxDenseRows];
+    int n_extras, n_dense;
+    int extras[kMaxExtras];
+    float c0;
+    size_t off_lo, off_kind, off_tabA, off_extraA, off_denseA, off_Arow;
 };
 
 hipError_t launch_dense(const FwdArgs& a, int songs_per_group, bool f16, hipStream_t st);
@@ -52,8 +66,11 @@ hipError_t launch_banded(const FwdArgs& a, bool f16, hipStream_t st);
 hipError_t launch_backtrace(BtArgs a, hipStream_t st);
 hipError_t launch_voicing_map(const int32_t* states, int64_t n, int32_t n_bins, uint8_t* voiced, int32_t* bins,
                               hipStream_t st);
-hipError_t launch_scan_selftest(const float* vals, int n_waves, int rev, float* out_v, int32_t* out_i,
+hipError_t launch_scan_selftest(const float* vals, int n_waves, int mode, float* out_v, int32_t* out_i,
                                 hipStream_t st);
-int backtrace_tile_rows(int SPSI);
+int backtrace_tile_rows(int SD);
+constexpr int kBtWarm = 256;       // warm-up frames of a speculative chunk
+constexpr int kBtMaxChunks = 32;
+int backtrace_chunks(int64_t B, int T);
 
 }  // namespace vit

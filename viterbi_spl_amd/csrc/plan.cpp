@@ -113,6 +113,13 @@ BandedPlan analyze_banded(const float* A, int S) {
             if (!inside && !is_extra(i) && f2u(A[(size_t)j * S + i]) != c0) return bp;
         }
     }
+    // near-diagonal windows: lo[j] is an affine function of j (lets the back-trace skip a table lookup)
+    for (int off = 0; off <= W && !bp.lo_affine; ++off) {
+        bool all = true;
+        for (int j = 0; j < S && all; ++j)
+            if (bp.kind[j] == -1) all = bp.lo[j] == std::max(0, std::min(j - off, S - W));
+        if (all) { bp.lo_affine = true; bp.lo_off = off; }
+    }
     bp.ok = true;
     return bp;
 }
@@ -133,6 +140,7 @@ ImageLayout make_layout(int S, const BandedPlan& bp) {
     L.off_tabA = off;   off = align256(off + sizeof(float) * (size_t)std::max(L.W, 1) * L.SP);
     L.off_extraA = off; off = align256(off + sizeof(float) * kMaxExtras * L.SP);
     L.off_denseA = off; off = align256(off + sizeof(float) * kMaxDenseRows * L.SP);
+    L.off_Arow = off;   off = align256(off + sizeof(float) * (size_t)S * L.SP);
     L.bytes = off;
     return L;
 }
@@ -152,6 +160,10 @@ void fill_image(const float* A, const float* log_pi, const BandedPlan& bp, const
                 const int i = 4 * q + r;
                 A4[((size_t)q * SP + j) * 4 + r] = (j < S && i < S) ? A[(size_t)j * S + i] : ninf;
             }
+
+    float* Arow = reinterpret_cast<float*>(image + L.off_Arow);
+    for (int j = 0; j < S; ++j)
+        for (int i = 0; i < SP; ++i) Arow[(size_t)j * SP + i] = i < S ? A[(size_t)j * S + i] : ninf;
 
     int32_t* lo = reinterpret_cast<int32_t*>(image + L.off_lo);
     int32_t* kind = reinterpret_cast<int32_t*>(image + L.off_kind);

@@ -39,6 +39,8 @@ struct BandedPlan {
     int W = 0;                // window width the kernel evaluates (16/32/64/128)
     std::vector<int32_t> lo;  // [SP] first source of the evaluated window (lo + W <= S)
     std::vector<int32_t> kind;// [SP] -1 banded row, d >= 0 dense row d, -2 padding
+    bool lo_affine = false;   // lo[j] == clamp(j - lo_off, 0, S - W) for every banded row
+    int lo_off = 0;
 };
 
 // Analyse logA_T ([S,S] row-major, row j = into target j).
@@ -55,6 +57,7 @@ struct ImageLayout {
     size_t off_tabA = 0;     // float [W][SP]       tabA[w][j] = logA_T[j][lo_j + w]
     size_t off_extraA = 0;   // float [4][SP]       extraA[k][j] = logA_T[j][extras[k]]
     size_t off_denseA = 0;   // float [4][SP]       denseA[d][i] = logA_T[dense_rows[d]][i]
+    size_t off_Arow = 0;     // float [S][SP]       row-major copy (row j = into target j) for the back-trace
     size_t bytes = 0;
 };
 

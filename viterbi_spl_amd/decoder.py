@@ -140,7 +140,7 @@ class ViterbiDecoder:
             elif phase == "forward":
                 rc = lib.vit_forward(self._plan, logE.data_ptr(), dt, B, T, len_ptr, ws_ptr, ws_bytes, ll_ptr, a, stream)
             elif phase == "backtrace":
-                rc = lib.vit_backtrace(self._plan, B, T, len_ptr, ws_ptr, ws_bytes, states.data_ptr(), stream)
+                rc = lib.vit_backtrace(self._plan, B, T, len_ptr, ws_ptr, ws_bytes, states.data_ptr(), a, stream)
             else:
                 raise ValueError(phase)
         _lib.check(rc, f"vit_{phase if phase != 'both' else 'decode'}")
