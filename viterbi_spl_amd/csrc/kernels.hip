@@ -26,6 +26,8 @@
 namespace vit {
 
 constexpr int kBig = 0x7fffffff;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct VI {
     float v;
@@ -67,20 +69,26 @@ __device__ __forceinline__ VI wave_scan(VI x) {
 }
 
 // ---- value-only wave primitives
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_max_step(float x) {
-    // lanes without a valid source (or in a masked row) read themselves: max(x, x) = x
-    const float s = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, ROW_MASK, 0xf, false));
-    return fmaxf(x, s);
-}
-// inclusive prefix max over lanes 0..lane
+// Inclusive prefix max over lanes 0..lane: six v_max_f32 with a DPP source operand
+// (row_shr:1/2/4/8, row_bcast:15 on rows 1,3, row_bcast:31 on rows 2,3).  A lane whose DPP source
+// is invalid or whose row is masked is not written and keeps its own value.  The s_nop 1 pairs are
+// the two wait states a DPP read of a just-written VGPR needs.
 __device__ __forceinline__ float wave_scan_max(float x) {
-    x = dpp_max_step<0x111, 0xf>(x);
-    x = dpp_max_step<0x112, 0xf>(x);
-    x = dpp_max_step<0x114, 0xf>(x);
-    x = dpp_max_step<0x118, 0xf>(x);
-    x = dpp_max_step<0x142, 0xa>(x);
-    x = dpp_max_step<0x143, 0xc>(x);
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(x));
     return x;
 }
 // lane l <- x[l-1], lane 0 <- fill   (wave_shr:1)
@@ -233,10 +241,12 @@ __global__ void __launch_bounds__(dense_max_threads(NS)) dense_forward_kernel(Fw
 //   wave  NWT       prefix-max scan over all sources (NWT per lane)
 //   wave  NWT+1     suffix-max scan (lanes hold the sources in descending blocks)
 //   wave  NWT+2     dense rows
+// A SIMD retires one wave64 VALU instruction per 4 cycles, shared by the waves resident on it, so
+// the frame time is set by the VALU instruction count of the busiest SIMD plus the two barriers.
 // Two workgroup barriers per frame; emission rows are fetched two frames ahead.
 // ---------------------------------------------------------------------------------------
-template <int W, int NWT, typename ET>
-__global__ void __launch_bounds__((NWT + 3) * 64) banded_forward_kernel(FwdArgs a) {
+template <int W, int NWT, bool DW, typename ET>
+__global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kernel(FwdArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NP = NWT * 64;
     constexpr int EPL = NWT;
@@ -281,7 +291,8 @@ __global__ void __launch_bounds__((NWT + 3) * 64) banded_forward_kernel(FwdArgs 
 #pragma unroll
         for (int k = 0; k < kMaxExtras; ++k) xa[k] = xaT[(size_t)k * SP + jc];
     }
-    const int role = wv - NWT;                 // 0 prefix, 1 suffix, 2 dense rows
+    const int role = wv - NWT;                 // 0 prefix, 1 suffix, 2 dense rows (DW) -- else the suffix wave reduces them
+    constexpr int kDenseRole = DW ? 2 : 1;
     const int blk = role == 1 ? 63 - lane : lane;
     const int i0 = blk * EPL;
     bool smask[EPL];
@@ -297,7 +308,7 @@ __global__ void __launch_bounds__((NWT + 3) * 64) banded_forward_kernel(FwdArgs 
             smask[e] = m;
 #pragma unroll
             for (int d = 0; d < kMaxDenseRows; ++d)
-                dA[d][e] = (role == 2 && i < S && d < nd) ? daT[(size_t)d * SP + i] : -INFINITY;
+                dA[d][e] = (role == kDenseRole && i < S && d < nd) ? daT[(size_t)d * SP + i] : -INFINITY;
         }
     }
 
@@ -330,8 +341,16 @@ __global__ void __launch_bounds__((NWT + 3) * 64) banded_forward_kernel(FwdArgs 
     asm volatile("" ::"v"(lo), "v"(kind), "v"(e_a), "v"(e_b));
     __syncthreads();
 
+    unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0;   // timing experiments only (dbg & 256)
+    auto stamp = [&]() -> unsigned long long {
+        unsigned long long v;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");
+        return v;
+    };
     auto frame = [&](const int t, float& e_slot) {
         float m = -INFINITY;
+        const bool prof = (dbg & 256) != 0;
+        const unsigned long long s0 = prof ? stamp() : 0ull;
         if (is_target) {
             // ---- window max (reads delta_{t-1}); four independent max3 chains
             float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
@@ -341,10 +360,17 @@ __global__ void __launch_bounds__((NWT + 3) * 64) banded_forward_kernel(FwdArgs 
             if (!(dbg & 1)) {
 #pragma unroll
                 for (int w = 0; w + 7 < W; w += 8) {
-                    m0 = fmaxf(fmaxf(m0, dl[lo + w + 0] + aw[w + 0]), dl[lo + w + 1] + aw[w + 1]);
-                    m1 = fmaxf(fmaxf(m1, dl[lo + w + 2] + aw[w + 2]), dl[lo + w + 3] + aw[w + 3]);
-                    m2 = fmaxf(fmaxf(m2, dl[lo + w + 4] + aw[w + 4]), dl[lo + w + 5] + aw[w + 5]);
-                    m3 = fmaxf(fmaxf(m3, dl[lo + w + 6] + aw[w + 6]), dl[lo + w + 7] + aw[w + 7]);
+                    const f32x4 da{dl[lo + w + 0], dl[lo + w + 1], dl[lo + w + 2], dl[lo + w + 3]};
+                    const f32x4 db{dl[lo + w + 4], dl[lo + w + 5], dl[lo + w + 6], dl[lo + w + 7]};
+                    // v_pk_add_f32: two fl32 adds per instruction (each lane still rounds separately)
+                    const f32x2 c0_ = f32x2{da.x, da.y} + f32x2{aw[w + 0], aw[w + 1]};
+                    const f32x2 c1_ = f32x2{da.z, da.w} + f32x2{aw[w + 2], aw[w + 3]};
+                    const f32x2 c2_ = f32x2{db.x, db.y} + f32x2{aw[w + 4], aw[w + 5]};
+                    const f32x2 c3_ = f32x2{db.z, db.w} + f32x2{aw[w + 6], aw[w + 7]};
+                    m0 = fmaxf(fmaxf(m0, c0_.x), c0_.y);
+                    m1 = fmaxf(fmaxf(m1, c1_.x), c1_.y);
+                    m2 = fmaxf(fmaxf(m2, c2_.x), c2_.y);
+                    m3 = fmaxf(fmaxf(m3, c3_.x), c3_.y);
                 }
             }
             m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
@@ -366,31 +392,36 @@ __global__ void __launch_bounds__((NWT + 3) * 64) banded_forward_kernel(FwdArgs 
                 for (int e = 0; e < EPL; ++e) Pv[i0 + e + 1] = fmaxf(ex, p[e]);
                 // floor maximum over delta_{t-1}: lets the back-trace skip the floor candidates
                 if (lane == 63 && !(dbg & 8)) a.fmax[(size_t)song * T + (t - 1)] = inc;
-            } else if (role == 1) {
-                float p[EPL];
-                float run = -INFINITY;
-#pragma unroll
-                for (int e = EPL - 1; e >= 0; --e) {
-                    run = fmaxf(run, smask[e] ? -INFINITY : d[e] + c0);
-                    p[e] = run;
-                }
-                const float ex = wave_shift_up(wave_scan_max(run), -INFINITY);  // sources of all higher blocks
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) Sv[i0 + e] = fmaxf(ex, p[e]);
             } else {
+                if (role == 1) {
+                    float p[EPL];
+                    float run = -INFINITY;
 #pragma unroll
-                for (int dr = 0; dr < kMaxDenseRows; ++dr) {
-                    if (dr < nd) {
-                        float run = -INFINITY;
+                    for (int e = EPL - 1; e >= 0; --e) {
+                        run = fmaxf(run, smask[e] ? -INFINITY : d[e] + c0);
+                        p[e] = run;
+                    }
+                    const float ex = wave_shift_up(wave_scan_max(run), -INFINITY);  // sources of all higher blocks
 #pragma unroll
-                        for (int e = 0; e < EPL; ++e) run = fmaxf(run, d[e] + dA[dr][e]);
-                        run = wave_max_all(run);
-                        if (lane == 0) Dv[dr] = run;
+                    for (int e = 0; e < EPL; ++e) Sv[i0 + e] = fmaxf(ex, p[e]);
+                }
+                if (role == kDenseRole) {
+#pragma unroll
+                    for (int dr = 0; dr < kMaxDenseRows; ++dr) {
+                        if (dr < nd) {
+                            float dm = -INFINITY;
+#pragma unroll
+                            for (int e = 0; e < EPL; ++e) dm = fmaxf(dm, d[e] + dA[dr][e]);
+                            dm = wave_max_all(dm);
+                            if (lane == 0) Dv[dr] = dm;
+                        }
                     }
                 }
             }
         }
+        const unsigned long long s1 = prof ? stamp() : 0ull;
         __syncthreads();
+        const unsigned long long s2 = prof ? stamp() : 0ull;
 
         if (is_target && !(dbg & 4)) {
             m = fmaxf(fmaxf(m, Pv[lo]), Sv[lo + W]);
@@ -400,12 +431,19 @@ __global__ void __launch_bounds__((NWT + 3) * 64) banded_forward_kernel(FwdArgs 
                 const float dn = m + e_slot;
                 dl[j] = dn;
                 if (!(dbg & 8)) {
-                    hist[(size_t)t * SD + j] = dn;
-                    if (t + 2 < Tb) e_slot = load_e<ET>(E + (size_t)(t + 2) * S + j);
+                    float* __restrict__ hrow = hist + (size_t)t * SD;          // wave-uniform row bases:
+                    const ET* __restrict__ erow = E + (size_t)(t + 2) * S;      // scalar base + lane offset
+                    hrow[j] = dn;
+                    if (t + 2 < Tb) e_slot = load_e<ET>(erow + j);
                 }
             }
         }
+        const unsigned long long s3 = prof ? stamp() : 0ull;
         __syncthreads();
+        if (prof) {
+            const unsigned long long s4 = stamp();
+            ph0 += s1 - s0; ph1 += s2 - s1; ph2 += s3 - s2; ph3 += s4 - s3;
+        }
     };
     const unsigned long long clk0 = (dbg & 48) ? __builtin_amdgcn_s_memtime() : 0ull;
     const unsigned long long rt0 = (dbg & 48) ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -416,7 +454,12 @@ __global__ void __launch_bounds__((NWT + 3) * 64) banded_forward_kernel(FwdArgs 
     }
     if (t < Tb) frame(t, e_a);
 
-    terminal_argmax(is_target ? dl[j] : -INFINITY, j, tvalid, tot, NWT + 3, a.last_state, a.loglik, song);
+    terminal_argmax(is_target ? dl[j] : -INFINITY, j, tvalid, tot, NWT + (DW ? 3 : 2), a.last_state, a.loglik, song);
+    if ((dbg & 256) && lane == 0 && Tb > 1) {   // per-wave phase averages -> fmax[song][4*wave .. 4*wave+3]
+        float* o = a.fmax + (size_t)song * T + 4 * wv;
+        const float n = (float)(Tb - 1);
+        o[0] = (float)ph0 / n; o[1] = (float)ph1 / n; o[2] = (float)ph2 / n; o[3] = (float)ph3 / n;
+    }
     if ((dbg & 48) && tid == 0 && a.loglik) {  // timing experiments only: cycles (16) or 100 MHz ticks (32) per frame
         const unsigned long long d = (dbg & 16) ? __builtin_amdgcn_s_memtime() - clk0 : __builtin_amdgcn_s_memrealtime() - rt0;
         a.loglik[song] = (float)d / (float)(Tb > 1 ? Tb - 1 : 1);
@@ -434,7 +477,6 @@ __global__ void __launch_bounds__((NWT + 3) * 64) banded_forward_kernel(FwdArgs 
 // ---------------------------------------------------------------------------------------
 constexpr int kBtWaves = 4;
 constexpr int kBtVec = 12;  // float4 per lane per tile: K * SD <= 12 * 256 floats
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void bt_fetch(f32x4 (&stage)[kBtVec], const f32x4* __restrict__ rows, int nvec, int lane) {
 #pragma unroll
@@ -760,8 +802,13 @@ hipError_t launch_dense(const FwdArgs& a, int ns, bool f16, hipStream_t st) {
 template <int W, int NWT, typename ET>
 static hipError_t launch_banded_t(const FwdArgs& a, hipStream_t st) {
     constexpr int NP = NWT * 64;
-    const size_t lds = sizeof(float) * (NP + 2 * (NP + 1) + kMaxDenseRows) + sizeof(VI) * 16;
-    hipLaunchKernelGGL((banded_forward_kernel<W, NWT, ET>), dim3((int)a.B), dim3((NWT + 3) * 64), lds, st, a);
+    const size_t lds = sizeof(float) * (NP + 2 * (NP + 1) + kMaxDenseRows) + sizeof(VI) * 16 + 16;
+    // One workgroup per CU (B <= 256): the dense rows get their own wave (shortest critical wave).
+    // More songs than CUs: NWT + 2 waves put exactly two on each SIMD, so two workgroups share a CU.
+    if (a.B <= 256)
+        hipLaunchKernelGGL((banded_forward_kernel<W, NWT, true, ET>), dim3((int)a.B), dim3((NWT + 3) * 64), lds, st, a);
+    else
+        hipLaunchKernelGGL((banded_forward_kernel<W, NWT, false, ET>), dim3((int)a.B), dim3((NWT + 2) * 64), lds, st, a);
     return hipGetLastError();
 }
 

@@ -50,7 +50,7 @@ BandedPlan analyze_banded(const float* A, int S) {
     if (c0_rows < S / 2) return bp;
     float c0f;
     std::memcpy(&c0f, &c0, 4);
-    if (std::isnan(c0f)) return bp;
+    if ((c0 & 0x7f800000u) == 0x7f800000u && (c0 & 0x007fffffu) != 0u) return bp;  // NaN bit pattern
     bp.c0 = c0f;
 
     // 3. extra columns: exceptions shared by more than a quarter of the c0 rows
