@@ -34,7 +34,7 @@ class HostPlan:
         h = lib.vph_create(A.ctypes.data, pi.ctypes.data, S)
         info = np.zeros(16, np.int32)
         c0 = np.zeros(1, np.float32)
-        off = np.zeros(9, np.int64)
+        off = np.zeros(10, np.int64)
         lib.vph_info(h, info.ctypes.data, c0.ctypes.data)
         lib.vph_offsets(h, off.ctypes.data)
         img = np.zeros(int(off[7]), np.uint8)
@@ -58,92 +58,79 @@ class HostPlan:
         self.extraA = sec(5, np.float32, 4 * SP).reshape(4, SP)
         self.denseA = sec(6, np.float32, 4 * SP).reshape(4, SP)
         self.Arow = sec(8, np.float32, self.S * SP).reshape(self.S, SP)
-
-
-def _first_max_prefix(g, gi):
-    """inclusive scan, later element replaces only if strictly greater"""
-    S = len(g)
-    pv = np.empty(S, np.float32)
-    pi = np.empty(S, np.int64)
-    bv, bi = np.float32(-np.inf), BIG
-    for i in range(S):
-        if g[i] > bv:
-            bv, bi = g[i], gi[i]
-        pv[i], pi[i] = bv, bi
-    return pv, pi
-
-
-def _first_max_suffix(g, gi):
-    """scan from the top; the next lower index replaces on >= (so the lowest index wins ties)"""
-    S = len(g)
-    sv = np.empty(S, np.float32)
-    si = np.empty(S, np.int64)
-    bv, bi = np.float32(-np.inf), BIG
-    for i in range(S - 1, -1, -1):
-        if g[i] >= bv:
-            bv, bi = g[i], gi[i]
-        sv[i], si[i] = bv, bi
-    return sv, si
+        self.rowc = sec(9, np.float32, SP)
 
 
 def replay_banded(plan: HostPlan, logE):
-    """Returns (states int64[T], loglik, final delta[S]) following banded_forward_kernel step by step."""
+    """Follows the GPU kernels step by step on the host.
+
+    Forward (banded_forward_kernel): value-only; per target the max of the W window sums, of
+    fl(max(prefix-max, suffix-max of the RAW delta) + c_j) and of the extra-column sums; dense rows
+    take the max over every source.  The delta row of every frame is kept.
+    Back-trace (lazy_backtrace_kernel): for the path state j at t+1 rebuild every candidate
+    fl(delta_t[i] + logA_T[j][i]) from the plan tables and take the LOWEST index attaining the max;
+    the fast path (window + extras only) is taken when fl(max_i delta_t[i] + c_j) < window max.
+    Returns (states int64[T], loglik, final delta[S])."""
     assert plan.ok
     S, W = plan.S, plan.W
     logE = np.ascontiguousarray(logE, np.float32)
     T = logE.shape[0]
-    delta = (plan.log_pi[:S] + logE[0]).astype(np.float32)
-    psi = np.zeros((T, S), np.int64)
     lo = plan.lo[:S].astype(np.int64)
     kind = plan.kind[:S]
+    rowc = plan.rowc[:S]
     win_idx = lo[:, None] + np.arange(W)[None, :]            # [S,W]
     tab = plan.tabA[:, :S].T                                  # [S,W]
     masked = np.zeros(S, bool)
     masked[plan.extras] = True
-    ar = np.arange(S)
+    ninf = np.float32(-np.inf)
+
+    hist = np.empty((T, S), np.float32)
+    dmax = np.empty(T, np.float32)
+    delta = (plan.log_pi[:S] + logE[0]).astype(np.float32)
+    hist[0] = delta
     for t in range(1, T):
-        g = np.where(masked, np.float32(-np.inf), (delta + plan.c0).astype(np.float32))
-        gi = np.where(masked, BIG, ar)
-        pv, pi = _first_max_prefix(g, gi)
-        sv, si = _first_max_suffix(g, gi)
-        cand = (delta[win_idx] + tab).astype(np.float32)
-        warg = np.argmax(cand, axis=1)
-        wbest = cand[ar, warg]
-        new = np.empty(S, np.float32)
-        for j in range(S):
-            av, ai = np.float32(-np.inf), BIG
-            if kind[j] == -1:
-                if lo[j] > 0 and pv[lo[j] - 1] > av:
-                    av, ai = pv[lo[j] - 1], pi[lo[j] - 1]
-                wv = wbest[j]
-                wi = BIG if not (wv > -np.inf) else lo[j] + warg[j]
-                if wv > av:
-                    av, ai = wv, wi
-                qs = lo[j] + W
-                if qs < S and sv[qs] > av:
-                    av, ai = sv[qs], si[qs]
-                for k, x in enumerate(plan.extras):
-                    v = np.float32(delta[x] + plan.extraA[k, j])
-                    if v > av or (v == av and x < ai and ai != BIG):
-                        av, ai = v, x
-            else:
-                d = kind[j]
-                c = (delta + plan.denseA[d, :S]).astype(np.float32)
-                ai = int(np.argmax(c))
-                av = c[ai]
-                if not (av > -np.inf):
-                    ai = BIG
-            if ai == BIG:
-                ai = 0
-            psi[t, j] = ai
-            new[j] = av + logE[t, j]
-        delta = new
+        raw = np.where(masked, ninf, delta)
+        pv = np.concatenate([[ninf], np.maximum.accumulate(raw)])          # pv[q] = max raw[:q]
+        sv = np.concatenate([np.maximum.accumulate(raw[::-1])[::-1], [ninf]])  # sv[q] = max raw[q:]
+        dmax[t - 1] = pv[S]
+        m = np.max((delta[win_idx] + tab).astype(np.float32), axis=1)
+        outside = (np.maximum(pv[lo], sv[lo + W]) + rowc).astype(np.float32)
+        m = np.maximum(m, outside)
+        for k, x in enumerate(plan.extras):
+            m = np.maximum(m, (delta[x] + plan.extraA[k, :S]).astype(np.float32))
+        for j in np.nonzero(kind >= 0)[0]:
+            m[j] = np.max((delta + plan.denseA[kind[j], :S]).astype(np.float32))
+        delta = (m + logE[t]).astype(np.float32)
+        hist[t] = delta
+
     s = int(np.argmax(delta))
     path = np.empty(T, np.int64)
     path[-1] = s
+    ar = np.arange(S)
+    n_fast = 0
     for t in range(T - 2, -1, -1):
-        s = psi[t + 1, s]
+        d = hist[t]
+        j = s
+        if kind[j] == -1:
+            cand_i = list(range(lo[j], lo[j] + W)) + list(plan.extras)
+            cand_v = [np.float32(d[lo[j] + w] + plan.tabA[w, j]) for w in range(W)] + \
+                     [np.float32(d[x] + plan.extraA[k, j]) for k, x in enumerate(plan.extras)]
+            m = max(cand_v) if cand_v else ninf
+            if np.float32(dmax[t] + rowc[j]) < m:              # fast path: no row-constant candidate can tie
+                s = min(i for i, v in zip(cand_i, cand_v) if v == m)
+                n_fast += 1
+                path[t] = s
+                continue
+            excl = masked | ((ar >= lo[j]) & (ar < lo[j] + W))
+            vf = np.where(excl, ninf, (d + rowc[j]).astype(np.float32))
+            m = max(m, np.max(vf))
+            idx = [i for i, v in zip(cand_i, cand_v) if v == m] + list(np.nonzero(vf == m)[0])
+            s = int(min(idx)) if idx else 0
+        else:
+            v = (d + plan.denseA[kind[j], :S]).astype(np.float32)
+            s = int(np.argmax(v))
         path[t] = s
+    replay_banded.last_fast_fraction = n_fast / max(T - 1, 1)
     return path, delta[path[-1]], delta
 
 

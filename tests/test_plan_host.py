@@ -12,8 +12,9 @@ def test_tonet_structure_is_proven(golden):
     plan = HostPlan(p["tonet361_logA_T"], p["tonet361_log_pi"])
     assert plan.ok and plan.S == 361 and plan.SP == 384
     assert plan.max_window == 29 and plan.W == 32
-    assert plan.extras == [360] and plan.dense_rows == [360]
+    assert plan.extras == [360] and plan.dense_rows == []      # the unvoiced row is banded with its own constant
     assert plan.c0 == np.float32(synth.LOG_TINY32)
+    assert np.all(plan.rowc[:360] == np.float32(synth.LOG_TINY32)) and plan.rowc[360] == p["tonet361_logA_T"][360, 0]
     assert np.all(plan.lo[:361] + plan.W <= 361) and np.all(plan.lo[:361] >= 0)
 
 
@@ -21,7 +22,7 @@ def test_msnet_real_parameters_are_banded(golden):
     p = golden["params"]
     plan = HostPlan(p["msnet321_logA_T"], p["msnet321_log_pi"])
     assert plan.ok and plan.max_window == 25 and plan.W == 32
-    assert plan.extras == [320] and plan.dense_rows == [320]
+    assert plan.extras == [320] and plan.dense_rows == []
 
 
 def test_unstructured_matrices_fall_back(golden):

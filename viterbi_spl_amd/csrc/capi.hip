@@ -175,6 +175,7 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
     a.off_tabA = plan->L.off_tabA;
     a.off_extraA = plan->L.off_extraA;
     a.off_denseA = plan->L.off_denseA;
+    a.off_rowc = plan->L.off_rowc;
 
     hipError_t e;
     if (algo == VIT_ALGO_BANDED) {
@@ -231,6 +232,7 @@ int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* len
     b.off_extraA = plan->L.off_extraA;
     b.off_denseA = plan->L.off_denseA;
     b.off_Arow = plan->L.off_Arow;
+    b.off_rowc = plan->L.off_rowc;
     hipError_t e = vit::launch_backtrace(b, (hipStream_t)stream);
     return e == hipSuccess ? VIT_OK : hip_fail(e);
 }

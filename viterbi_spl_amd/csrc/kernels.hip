@@ -228,13 +228,13 @@ __global__ void __launch_bounds__(dense_max_threads(NS)) dense_forward_kernel(Fw
 // ---------------------------------------------------------------------------------------
 // Banded forward kernel: one song per workgroup, value-only.
 //
-// For a banded target j (window [lo_j, lo_j+W), shared constant c0, extra columns X):
-//   m_j = max( Pv[lo_j],                                      prefix max of fl(delta_i + c0), i < lo_j
-//              max_w fl(delta_{lo_j+w} + logA_T[j][lo_j+w]),   W register-resident window entries
-//              Sv[lo_j+W],                                     suffix max of fl(delta_i + c0), i >= lo_j+W
-//              fl(delta_x + logA_T[j][x]), x in X )
-// (extra columns are excluded from the c0 scans).  Dense rows are a full max over all sources.
-// The max of the same fl32 sums the dense recursion forms, so delta is bit-identical.
+// For a banded target j (window [lo_j, lo_j+W), row constant c_j, extra columns X):
+//   m_j = max( max_w fl(delta_{lo_j+w} + logA_T[j][lo_j+w]),   W register-resident window entries
+//              fl( max(Pv[lo_j], Sv[lo_j+W]) + c_j ),          Pv/Sv: prefix / suffix max of the RAW delta
+//              fl(delta_x + logA_T[j][x]), x in X )             (extra columns are excluded from the scans)
+// Rounding is monotone, so max_i fl(delta_i + c_j) = fl(max_i delta_i + c_j): the value equals the max
+// of the fl32 sums the dense recursion forms, and delta is bit-identical.  Dense rows (none for the
+// reference's matrices) are a full max over all sources.
 //
 // Wave roles (NWT target waves, 64*NWT >= S):
 //   waves 0..NWT-1  one thread per target: window max, merge, delta_t, history row
@@ -264,7 +264,6 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
     const int Tb = song_length(a.lengths, song, T);
     const ET* __restrict__ E = reinterpret_cast<const ET*>(a.logE) + (size_t)song * T * S;
     float* __restrict__ hist = a.hist + (size_t)song * T * SD;
-    const float c0 = a.c0;
     const int nx = a.n_extras, nd = a.n_dense;
     const int dbg = a.debug;
 
@@ -274,6 +273,7 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
     const bool tvalid = is_target && j < S;
     const int jc = j < SP ? j : 0;
     int lo = 0, kind = -2;
+    float cj = 0.f;
     float aw[W];
     float xa[kMaxExtras];
     int xcol[kMaxExtras];
@@ -282,6 +282,7 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
 #pragma unroll
     for (int w = 0; w < W; ++w) aw[w] = 0.f;
     if (is_target) {
+        cj = reinterpret_cast<const float*>(a.image + a.off_rowc)[jc];
         lo = reinterpret_cast<const int32_t*>(a.image + a.off_lo)[jc];
         kind = j < SP ? reinterpret_cast<const int32_t*>(a.image + a.off_kind)[jc] : -2;
         const float* __restrict__ tab = reinterpret_cast<const float*>(a.image + a.off_tabA);
@@ -338,7 +339,7 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
 #pragma unroll
         for (int d = 0; d < kMaxDenseRows; ++d) asm volatile("" ::"v"(dA[d][e]));
     }
-    asm volatile("" ::"v"(lo), "v"(kind), "v"(e_a), "v"(e_b));
+    asm volatile("" ::"v"(lo), "v"(kind), "v"(cj), "v"(e_a), "v"(e_b));
     __syncthreads();
 
     unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0;   // timing experiments only (dbg & 256)
@@ -383,14 +384,14 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
                 float run = -INFINITY;
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
-                    run = fmaxf(run, smask[e] ? -INFINITY : d[e] + c0);
+                    run = fmaxf(run, smask[e] ? -INFINITY : d[e]);
                     p[e] = run;
                 }
                 const float inc = wave_scan_max(run);
                 const float ex = wave_shift_up(inc, -INFINITY);                 // sources of all lower lanes
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) Pv[i0 + e + 1] = fmaxf(ex, p[e]);
-                // floor maximum over delta_{t-1}: lets the back-trace skip the floor candidates
+                // max of delta_{t-1} over the non-extra sources: bounds every row-constant candidate in the back-trace
                 if (lane == 63 && !(dbg & 8)) a.fmax[(size_t)song * T + (t - 1)] = inc;
             } else {
                 if (role == 1) {
@@ -398,7 +399,7 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
                     float run = -INFINITY;
 #pragma unroll
                     for (int e = EPL - 1; e >= 0; --e) {
-                        run = fmaxf(run, smask[e] ? -INFINITY : d[e] + c0);
+                        run = fmaxf(run, smask[e] ? -INFINITY : d[e]);
                         p[e] = run;
                     }
                     const float ex = wave_shift_up(wave_scan_max(run), -INFINITY);  // sources of all higher blocks
@@ -424,7 +425,7 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
         const unsigned long long s2 = prof ? stamp() : 0ull;
 
         if (is_target && !(dbg & 4)) {
-            m = fmaxf(fmaxf(m, Pv[lo]), Sv[lo + W]);
+            m = fmaxf(m, fmaxf(Pv[lo], Sv[lo + W]) + cj);
             const float dres = Dv[kind >= 0 ? kind : 0];
             if (kind >= 0) m = dres;
             if (tvalid) {
@@ -503,7 +504,8 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
     float* fms = reinterpret_cast<float*>(outs + kBtWaves * 64);
     int32_t* loL = reinterpret_cast<int32_t*>(fms + kBtWaves * 64);
     int32_t* kindL = loL + SP;
-    float* tabX = reinterpret_cast<float*>(kindL + SP);   // [(W + kMaxExtras)][SP]
+    float* rowcL = reinterpret_cast<float*>(kindL + SP);  // [SP] row constants
+    float* tabX = rowcL + SP;                             // [(W + kMaxExtras)][SP]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform for the compiler
@@ -512,7 +514,8 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
         const int32_t* gk = reinterpret_cast<const int32_t*>(a.image + a.off_kind);
         const float* gx = reinterpret_cast<const float*>(a.image + a.off_extraA);
         const float* gt = reinterpret_cast<const float*>(a.image + a.off_tabA);
-        for (int k = tid; k < SP; k += kBtWaves * 64) { loL[k] = gl[k]; kindL[k] = gk[k]; }
+        const float* gc = reinterpret_cast<const float*>(a.image + a.off_rowc);
+        for (int k = tid; k < SP; k += kBtWaves * 64) { loL[k] = gl[k]; kindL[k] = gk[k]; rowcL[k] = gc[k]; }
         for (int k = tid; k < W * SP; k += kBtWaves * 64) tabX[k] = gt[k];
         for (int k = tid; k < kMaxExtras * SP; k += kBtWaves * 64) tabX[W * SP + k] = gx[k];
     }
@@ -528,7 +531,6 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
     const float* __restrict__ hist = a.hist + (size_t)song * T * SD;
     const float* __restrict__ fmaxg = a.fmax + (size_t)song * T;
     const float* __restrict__ Arow = reinterpret_cast<const float*>(a.image + a.off_Arow);
-    const float c0 = a.c0;
     float* tile = reinterpret_cast<float*>(tiles + wv * kBtVec * 64);
     int32_t* out = outs + wv * 64;
     float* fm = fms + wv * 64;
@@ -602,7 +604,7 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
                 float v = -INFINITY;
                 if (lane < WX) v = row[src] + tabX[lane * SP + jj];
                 const float m = wave_max_all(v);
-                const float mf = fm[r];          // max_i fl(delta_t[i] + c0): bound on every floor candidate
+                const float mf = fm[r] + rowcL[jj];   // fl(max_i delta_t[i] + c_jj) bounds every row-constant candidate
                 if (mf < m || (a.debug & 64)) {  // no floor candidate can tie or win
                     const unsigned long long mk = __ballot(v == m);
                     unsigned idx = 0x7fffffffu;
@@ -627,13 +629,14 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
                 }
                 float vw = -INFINITY;
                 if (kd == -1) {
+                    const float cjj = rowcL[jj];
                     const int src = lane < W ? lo + lane : xsrc;
                     if (lane < WX) vw = row[src] + tabX[lane * SP + jj];
 #pragma unroll
                     for (int e = 0; e < EPL; ++e) {
                         const int i = e * 64 + lane;
                         const bool excl = isx[e] || (unsigned)(i - lo) < (unsigned)W;
-                        vf[e] = excl ? -INFINITY : d[e] + c0;
+                        vf[e] = excl ? -INFINITY : d[e] + cjj;
                     }
                     if (WX > 64) {  // extras did not fit beside the window: fold them into the strided part
 #pragma unroll
@@ -803,9 +806,10 @@ template <int W, int NWT, typename ET>
 static hipError_t launch_banded_t(const FwdArgs& a, hipStream_t st) {
     constexpr int NP = NWT * 64;
     const size_t lds = sizeof(float) * (NP + 2 * (NP + 1) + kMaxDenseRows) + sizeof(VI) * 16 + 16;
-    // One workgroup per CU (B <= 256): the dense rows get their own wave (shortest critical wave).
-    // More songs than CUs: NWT + 2 waves put exactly two on each SIMD, so two workgroups share a CU.
-    if (a.B <= 256)
+    // NWT + 2 waves put exactly two on each SIMD at S = 361 and let two workgroups share a CU.  Only a
+    // plan with dense rows, run at one workgroup per CU, gets a separate wave for them (it would
+    // otherwise lengthen the suffix wave, the critical one).
+    if (a.n_dense > 0 && a.B <= 256)
         hipLaunchKernelGGL((banded_forward_kernel<W, NWT, true, ET>), dim3((int)a.B), dim3((NWT + 3) * 64), lds, st, a);
     else
         hipLaunchKernelGGL((banded_forward_kernel<W, NWT, false, ET>), dim3((int)a.B), dim3((NWT + 2) * 64), lds, st, a);
@@ -856,7 +860,7 @@ int backtrace_tile_rows(int SD) {
 template <int NWT>
 static hipError_t launch_bt_t(const BtArgs& a, hipStream_t st) {
     size_t lds = sizeof(f32x4) * kBtWaves * kBtVec * 64 + sizeof(int32_t) * kBtWaves * 64 * 2;
-    if (a.banded) lds += sizeof(int32_t) * 2 * a.SP + sizeof(float) * (kMaxExtras + a.W) * a.SP;
+    if (a.banded) lds += sizeof(int32_t) * 2 * a.SP + sizeof(float) * (1 + kMaxExtras + a.W) * a.SP;
     const long long waves0 = (long long)a.B * a.chunks;
     hipLaunchKernelGGL((lazy_backtrace_kernel<NWT, 0>), dim3((int)((waves0 + kBtWaves - 1) / kBtWaves)), dim3(kBtWaves * 64),
                        lds, st, a);

@@ -27,7 +27,7 @@ struct FwdArgs {
     const void* logE;       // [B,T,S] f32 or f16
     const int64_t* lengths; // [B] or null
     float* hist;            // [B,T,SD] delta history (the reference's T1), SD = ceil(S/4)*4
-    float* fmax;            // [B,T] banded plan: fmax[t] = max_i fl(delta_t[i] + c0) over non-extra sources
+    float* fmax;            // [B,T] banded plan: fmax[t] = max_i delta_t[i] over the non-extra sources
     int32_t* last_state;    // [B]
     float* loglik;          // [B] or null
     int64_t B;
@@ -36,7 +36,7 @@ struct FwdArgs {
     int extras[kMaxExtras];
     float c0;
     int debug;              // timing-only ablation mask (VIT_DEBUG_FLAGS); 0 in production
-    size_t off_logpi, off_A4, off_lo, off_kind, off_tabA, off_extraA, off_denseA;
+    size_t off_logpi, off_A4, off_lo, off_kind, off_tabA, off_extraA, off_denseA, off_rowc;
 };
 
 struct BtArgs {
@@ -58,7 +58,7 @@ struct BtArgs {
     int n_extras, n_dense;
     int extras[kMaxExtras];
     float c0;
-    size_t off_lo, off_kind, off_tabA, off_extraA, off_denseA, off_Arow;
+    size_t off_lo, off_kind, off_tabA, off_extraA, off_denseA, off_Arow, off_rowc;
 };
 
 hipError_t launch_dense(const FwdArgs& a, int songs_per_group, bool f16, hipStream_t st);

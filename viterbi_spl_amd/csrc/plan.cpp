@@ -25,9 +25,10 @@ BandedPlan analyze_banded(const float* A, int S) {
     bp.SP = (S + 63) / 64 * 64;
     bp.lo.assign(bp.SP, 0);
     bp.kind.assign(bp.SP, -2);
+    bp.rowc.assign(bp.SP, 0.f);
     if (S < 32) return bp;  // nothing to gain; the dense kernel handles it
 
-    // 1. modal bit pattern of every row
+    // 1. modal bit pattern of every row = its row constant c_j
     std::vector<uint32_t> row_mode(S);
     std::vector<uint32_t> tmp(S);
     for (int j = 0; j < S; ++j) {
@@ -40,27 +41,22 @@ BandedPlan analyze_banded(const float* A, int S) {
             if (run > best_run) { best_run = run; best_val = tmp[i]; }
         }
         row_mode[j] = best_val;
+        if ((best_val & 0x7f800000u) == 0x7f800000u && (best_val & 0x007fffffu) != 0u) return bp;  // NaN
+        std::memcpy(&bp.rowc[j], &best_val, 4);
     }
-    // 2. the constant shared by most rows
     std::map<uint32_t, int> votes;
     for (int j = 0; j < S; ++j) votes[row_mode[j]]++;
     uint32_t c0 = row_mode[0];
     int c0_rows = 0;
     for (auto& kv : votes) if (kv.second > c0_rows) { c0_rows = kv.second; c0 = kv.first; }
-    if (c0_rows < S / 2) return bp;
-    float c0f;
-    std::memcpy(&c0f, &c0, 4);
-    if ((c0 & 0x7f800000u) == 0x7f800000u && (c0 & 0x007fffffu) != 0u) return bp;  // NaN bit pattern
-    bp.c0 = c0f;
+    std::memcpy(&bp.c0, &c0, 4);
 
-    // 3. extra columns: exceptions shared by more than a quarter of the c0 rows
+    // 2. extra columns: exceptions (w.r.t. the row's own constant) shared by more than a quarter of the rows
     std::vector<int> col_exc(S, 0);
-    for (int j = 0; j < S; ++j) {
-        if (row_mode[j] != c0) continue;
-        for (int i = 0; i < S; ++i) col_exc[i] += (f2u(A[(size_t)j * S + i]) != c0);
-    }
+    for (int j = 0; j < S; ++j)
+        for (int i = 0; i < S; ++i) col_exc[i] += (f2u(A[(size_t)j * S + i]) != row_mode[j]);
     std::vector<int> cand;
-    for (int i = 0; i < S; ++i) if (col_exc[i] > c0_rows / 4) cand.push_back(i);
+    for (int i = 0; i < S; ++i) if (col_exc[i] > S / 4) cand.push_back(i);
     if ((int)cand.size() > kMaxExtras) return bp;
     bp.n_extras = (int)cand.size();
     for (int k = 0; k < bp.n_extras; ++k) bp.extras[k] = cand[k];
@@ -69,15 +65,14 @@ BandedPlan analyze_banded(const float* A, int S) {
         return false;
     };
 
-    // 4. per-row exception windows
+    // 3. per-row exception windows; rows whose exceptions do not fit a window become dense rows
     std::vector<int> lo(S, 0), hi(S, 0);
     std::vector<int> dense;
     int max_window = 1;
     for (int j = 0; j < S; ++j) {
-        if (row_mode[j] != c0) { dense.push_back(j); continue; }
         int l = S, h = -1;
         for (int i = 0; i < S; ++i) {
-            if (is_extra(i) || f2u(A[(size_t)j * S + i]) == c0) continue;
+            if (is_extra(i) || f2u(A[(size_t)j * S + i]) == row_mode[j]) continue;
             l = std::min(l, i);
             h = std::max(h, i);
         }
@@ -92,7 +87,7 @@ BandedPlan analyze_banded(const float* A, int S) {
     for (int d = 0; d < bp.n_dense; ++d) bp.dense_rows[d] = dense[d];
     bp.max_window = max_window;
 
-    // 5. evaluated window width
+    // 4. evaluated window width
     int W = 0;
     for (int w : kWidths) if (w >= max_window) { W = w; break; }
     if (W == 0 || W > S || 2 * W > S) return bp;  // too wide to beat the dense kernel
@@ -104,13 +99,13 @@ BandedPlan analyze_banded(const float* A, int S) {
     }
     for (int d = 0; d < bp.n_dense; ++d) { bp.kind[dense[d]] = d; bp.lo[dense[d]] = 0; }
 
-    // 6. proof obligation, re-checked from the bits: outside [lo, lo+W) and the
-    //    extra columns every entry of a banded row equals c0.
+    // 5. proof obligation, re-checked from the bits: outside [lo, lo+W) and the extra columns every
+    //    entry of a banded row equals that row's constant.
     for (int j = 0; j < S; ++j) {
         if (bp.kind[j] != -1) continue;
         for (int i = 0; i < S; ++i) {
             const bool inside = i >= bp.lo[j] && i < bp.lo[j] + W;
-            if (!inside && !is_extra(i) && f2u(A[(size_t)j * S + i]) != c0) return bp;
+            if (!inside && !is_extra(i) && f2u(A[(size_t)j * S + i]) != row_mode[j]) return bp;
         }
     }
     // near-diagonal windows: lo[j] is an affine function of j (lets the back-trace skip a table lookup)
@@ -141,6 +136,7 @@ ImageLayout make_layout(int S, const BandedPlan& bp) {
     L.off_extraA = off; off = align256(off + sizeof(float) * kMaxExtras * L.SP);
     L.off_denseA = off; off = align256(off + sizeof(float) * kMaxDenseRows * L.SP);
     L.off_Arow = off;   off = align256(off + sizeof(float) * (size_t)S * L.SP);
+    L.off_rowc = off;   off = align256(off + sizeof(float) * L.SP);
     L.bytes = off;
     return L;
 }
@@ -173,8 +169,10 @@ void fill_image(const float* A, const float* log_pi, const BandedPlan& bp, const
     for (int j = 0; j < SP; ++j) { lo[j] = 0; kind[j] = -2; }
     for (int k = 0; k < kMaxExtras; ++k) for (int j = 0; j < SP; ++j) xa[(size_t)k * SP + j] = ninf;
     for (int d = 0; d < kMaxDenseRows; ++d) for (int j = 0; j < SP; ++j) da[(size_t)d * SP + j] = ninf;
+    float* rc = reinterpret_cast<float*>(image + L.off_rowc);
+    for (int j = 0; j < SP; ++j) rc[j] = 0.f;
     if (!bp.ok) return;
-    for (int j = 0; j < S; ++j) { lo[j] = bp.lo[j]; kind[j] = bp.kind[j]; }
+    for (int j = 0; j < S; ++j) { lo[j] = bp.lo[j]; kind[j] = bp.kind[j]; rc[j] = bp.rowc[j]; }
     for (int w = 0; w < L.W; ++w)
         for (int j = 0; j < SP; ++j)
             tab[(size_t)w * SP + j] = j < S ? A[(size_t)j * S + bp.lo[j] + w] : ninf;

@@ -8,13 +8,12 @@
 // reference's */viterbi_transition_post_processing.py are
 //   band(+/- d_max) + one dense row + one dense column, every other entry the
 //   single constant c = log(0 + tiny).
-// For a target row j whose entries outside a window [lo_j, hi_j] and outside a
-// few shared "extra" columns all equal the same constant c, the candidates
-// fl(delta_i + c) outside the window are the same numbers for every such row, so
-// their first-max is a prefix/suffix first-max scan evaluated at the window
-// edges.  Every value compared is one the dense recursion also computes, and
-// candidates are merged in increasing source order with a strict '>', so the
-// result is bit-identical to the dense recursion.
+// For a target row j whose entries outside a window [lo_j, lo_j+W) and outside a
+// few shared "extra" columns all equal one constant c_j, rounding is monotone, so
+//   max_{i outside} fl(delta_i + c_j) = fl( max_{i outside} delta_i + c_j ):
+// one prefix-max and one suffix-max scan over the raw delta vector, evaluated at
+// the window edges, replace S - W candidates per target.  Every value compared
+// is one the dense recursion also computes, so the result is bit-identical.
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -24,13 +23,14 @@ namespace vit {
 
 constexpr int kMaxExtras = 4;
 constexpr int kMaxDenseRows = 4;
-constexpr int kMaxWindow = 128;
+constexpr int kMaxWindow = 64;   // widest window the banded kernel is instantiated for
 
 struct BandedPlan {
     bool ok = false;          // the decomposition was proven for this matrix
     int S = 0;
     int SP = 0;               // S rounded up to a multiple of 64 (threads per workgroup)
-    float c0 = 0.f;           // the shared row constant (bit pattern compared exactly)
+    float c0 = 0.f;           // the most common row constant (informational)
+    std::vector<float> rowc;  // [SP] row constant c_j: every entry of row j outside its window and the extra columns
     int n_extras = 0;
     int extras[kMaxExtras] = {0, 0, 0, 0};
     int n_dense = 0;
@@ -58,6 +58,7 @@ struct ImageLayout {
     size_t off_extraA = 0;   // float [4][SP]       extraA[k][j] = logA_T[j][extras[k]]
     size_t off_denseA = 0;   // float [4][SP]       denseA[d][i] = logA_T[dense_rows[d]][i]
     size_t off_Arow = 0;     // float [S][SP]       row-major copy (row j = into target j) for the back-trace
+    size_t off_rowc = 0;     // float [SP]          row constants c_j
     size_t bytes = 0;
 };
 
