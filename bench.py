@@ -158,13 +158,19 @@ def main():
         achieved = fwd_bytes / (fwd_ms * 1e-3) / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
+        key = f"{algo}_B{B}_T{T}_S{S}_{'f16' if args.f16 else 'f32'}"
+        if os.path.exists(tf):       # PMC measurement of the same command, collected by scripts/pmc_traffic.sh
             try:
-                rec = json.load(open(tf))
-                key = f"{algo}_B{B}_T{T}_S{S}_{'f16' if args.f16 else 'f32'}"
-                traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tf)).get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        bt_traffic = None
+        if os.path.exists(tf):
+            try:
+                bt_traffic = json.load(open(tf)).get(key, {}).get("backtrace", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                bt_traffic = None
+        SD = (S + 3) // 4 * 4
         out = {
             "metric": "Viterbi Mframes/s at S=361 T=30k; achieved HBM GB/s vs peak",
             "value": value, "unit": "Mframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -179,8 +185,12 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": fwd_bytes, "avg_launch_ms": fwd_ms,
                          "bytes_per_frame": S * esize + S * 2,
-                         "note": "dense/banded recursions are fp32-VALU/latency bound, not HBM bound (DESIGN.md)"},
+                         "note": "algorithmic bytes per SURVEY 8d (emission row in + uint16 back-pointer row out); this "
+                                 "implementation stores the float32 delta row instead (lazy back-pointers, DESIGN.md), "
+                                 "and the recursion is fp32-VALU / latency bound, not HBM bound"},
             "kernels_ms": {"forward": fwd_ms, "backtrace": bt_ms},
+            "backtrace": {"algorithmic_bytes_per_launch": bt_bytes, "traffic": bt_traffic,
+                          "implementation_bytes_per_frame": SD * 4},
             "whole_path_bytes_per_frame": S * esize + S * 2 + 6,
             "whole_path_hbm_frac": value * 1e6 * (S * esize + S * 2 + 6) / 1e9 / (HBM_PEAK_GBS * world),
         }
