@@ -44,7 +44,8 @@ class HostPlan:
         self.n_extras, self.n_dense, self.max_window = int(info[4]), int(info[5]), int(info[6])
         self.extras = [int(x) for x in info[7:7 + self.n_extras]]
         self.dense_rows = [int(x) for x in info[11:11 + self.n_dense]]
-        self.S4 = int(info[15])
+        self.S4 = int(info[15]) & 0xFFFF
+        self.pair_ok = bool(int(info[15]) & 0x10000)
         self.c0 = np.float32(c0[0])
         SP, S4 = self.SP, self.S4
 

@@ -176,6 +176,9 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
     a.off_extraA = plan->L.off_extraA;
     a.off_denseA = plan->L.off_denseA;
     a.off_rowc = plan->L.off_rowc;
+    a.off_lo2 = plan->L.off_lo2;
+    a.off_tabP = plan->L.off_tabP;
+    a.pair_ok = plan->bp.ok && plan->bp.pair_ok ? 1 : 0;
 
     hipError_t e;
     if (algo == VIT_ALGO_BANDED) {

@@ -251,11 +251,18 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
     constexpr int NP = NWT * 64;
     constexpr int EPL = NWT;
     const int S = a.S, SP = a.SP, T = a.T, SD = a.SD;
-    float* dl = reinterpret_cast<float*>(smem);   // [NP]    delta_{t-1}; entries >= S stay -inf
-    float* Pv = dl + NP;                          // [NP+1]  Pv[q] = max_{i<q}  g_i
-    float* Sv = Pv + NP + 1;                      // [NP+1]  Sv[q] = max_{i>=q} g_i
+    // delta_{t-1} is kept as four copies shifted by 0..3 entries (entry m of copy c = delta[m + c], copy c
+    // at dls + c*DC + 4): every lane reads its window with aligned 16-byte LDS reads (256 B/clk instead of
+    // the 128 B/clk of 4-/8-byte reads, which bound the window phase) from the copy that makes its window
+    // start 16-byte aligned.  Each copy has 4 pad entries in front, so the four writes of a new delta value
+    // (entry j - c of copy c) need no bounds test.  Entries >= S stay -inf.
+    constexpr int DC = NP + 16;                   // copy stride = 16 banks mod 64: a 16-lane read group covers all 64 banks
+    float* dls = reinterpret_cast<float*>(smem);  // [4][DC]
+    float* dl = dls + 4;                          // copy 0 (unshifted)
+    float* Pv = dls + 4 * DC;                     // [NP+1]  Pv[q] = max_{i<q}  raw delta (extras excluded)
+    float* Sv = Pv + NP + 1;                      // [NP+1]  Sv[q] = max_{i>=q} raw delta
     float* Dv = Sv + NP + 1;                      // [4]     dense-row maxima
-    VI* tot = reinterpret_cast<VI*>(Dv + kMaxDenseRows);  // [16] terminal argmax scratch
+    VI* tot = reinterpret_cast<VI*>(Dv + kMaxDenseRows);  // [16] terminal argmax scratch (4*DC + 2*NP + 6 floats before: 8-byte aligned)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -314,13 +321,15 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
     }
 
     // ---------------- frame 0
+    for (int k = tid; k < 4 * DC; k += blockDim.x) dls[k] = -INFINITY;
+    __syncthreads();
     if (is_target) {
-        float d = -INFINITY;
         if (tvalid) {
-            d = reinterpret_cast<const float*>(a.image + a.off_logpi)[j] + load_e<ET>(E + j);
+            const float d = reinterpret_cast<const float*>(a.image + a.off_logpi)[j] + load_e<ET>(E + j);
             hist[j] = d;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dl[c * DC + j - c] = d;
         }
-        dl[j] = d;
     } else if (lane == 0) {
         if (role == 0) Pv[0] = -INFINITY;
         if (role == 1) Sv[NP] = -INFINITY;
@@ -359,10 +368,11 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
             for (int k = 0; k < kMaxExtras; ++k)
                 if (k < nx) m0 = fmaxf(m0, dl[xcol[k]] + xa[k]);
             if (!(dbg & 1)) {
+                // copy (lo & 3), entry (lo & ~3): delta[lo .. lo+W) as W/4 aligned 16-byte reads
+                const f32x4* __restrict__ win = reinterpret_cast<const f32x4*>(dl + (lo & 3) * DC + (lo & ~3));
 #pragma unroll
                 for (int w = 0; w + 7 < W; w += 8) {
-                    const f32x4 da{dl[lo + w + 0], dl[lo + w + 1], dl[lo + w + 2], dl[lo + w + 3]};
-                    const f32x4 db{dl[lo + w + 4], dl[lo + w + 5], dl[lo + w + 6], dl[lo + w + 7]};
+                    const f32x4 da = win[w / 4], db = win[w / 4 + 1];
                     // v_pk_add_f32: two fl32 adds per instruction (each lane still rounds separately)
                     const f32x2 c0_ = f32x2{da.x, da.y} + f32x2{aw[w + 0], aw[w + 1]};
                     const f32x2 c1_ = f32x2{da.z, da.w} + f32x2{aw[w + 2], aw[w + 3]};
@@ -430,7 +440,8 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
             if (kind >= 0) m = dres;
             if (tvalid) {
                 const float dn = m + e_slot;
-                dl[j] = dn;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) dl[c * DC + j - c] = dn;
                 if (!(dbg & 8)) {
                     float* __restrict__ hrow = hist + (size_t)t * SD;          // wave-uniform row bases:
                     const ET* __restrict__ erow = E + (size_t)(t + 2) * S;      // scalar base + lane offset
@@ -464,6 +475,196 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
     if ((dbg & 48) && tid == 0 && a.loglik) {  // timing experiments only: cycles (16) or 100 MHz ticks (32) per frame
         const unsigned long long d = (dbg & 16) ? __builtin_amdgcn_s_memtime() - clk0 : __builtin_amdgcn_s_memrealtime() - rt0;
         a.loglik[song] = (float)d / (float)(Tb > 1 ? Tb - 1 : 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Banded forward kernel, two targets per lane (the plan proved "pair windows": targets 2p and
+// 2p+1 both fit one window [lo2_p, lo2_p + W + 2)).  Same arithmetic as banded_forward_kernel;
+// the point is issue slots: a wave issues at most one instruction (of any kind) per 4-cycle SIMD
+// turn, and sharing the window reads between two targets needs 17 LDS reads + waits per pair
+// instead of 32, and only ceil(S/128) target waves (one per SIMD at S = 361) plus two scan waves.
+// ---------------------------------------------------------------------------------------
+template <int W, int NWT, typename ET>
+__global__ void __launch_bounds__(((NWT + 1) / 2 + 2) * 64) banded_pair_forward_kernel(FwdArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int NP = NWT * 64;           // padded state count (scan waves: NWT sources per lane)
+    constexpr int EPL = NWT;
+    constexpr int NPW = (NWT + 1) / 2;     // target waves: one lane per pair of targets
+    constexpr int WP = W + 2;              // common window of a pair
+    const int S = a.S, SP = a.SP, T = a.T, SD = a.SD;
+    float* dl = reinterpret_cast<float*>(smem);   // [NP]    delta_{t-1}; entries >= S stay -inf
+    float* Pv = dl + NP;                          // [NP+1]  Pv[q] = max_{i<q}  raw delta (extras excluded)
+    float* Sv = Pv + NP + 1;                      // [NP+1]  Sv[q] = max_{i>=q} raw delta
+    VI* tot = reinterpret_cast<VI*>(Sv + NP + 1);  // [16]; 3*NP + 2 floats precede it: 8-byte aligned
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int song = blockIdx.x;
+    const int Tb = song_length(a.lengths, song, T);
+    const ET* __restrict__ E = reinterpret_cast<const ET*>(a.logE) + (size_t)song * T * S;
+    float* __restrict__ hist = a.hist + (size_t)song * T * SD;
+    const int nx = a.n_extras;
+    const int dbg = a.debug;
+
+    // ---------------- per-role setup
+    const bool is_target = wv < NPW;
+    const int j0 = 2 * tid, j1 = 2 * tid + 1;          // this lane's two targets
+    const bool v0 = is_target && j0 < S, v1 = is_target && j1 < S;
+    const int jc0 = v0 ? j0 : 0, jc1 = v1 ? j1 : jc0;
+    int lo = 0;
+    float cj0 = 0.f, cj1 = 0.f;
+    float aw0[WP], aw1[WP];
+    float xa0[kMaxExtras], xa1[kMaxExtras];
+    int xcol[kMaxExtras];
+#pragma unroll
+    for (int k = 0; k < kMaxExtras; ++k) { xa0[k] = xa1[k] = -INFINITY; xcol[k] = a.extras[k]; }
+#pragma unroll
+    for (int w = 0; w < WP; ++w) aw0[w] = aw1[w] = 0.f;
+    if (is_target) {
+        lo = reinterpret_cast<const int32_t*>(a.image + a.off_lo2)[jc0 >> 1];
+        const float* __restrict__ rc = reinterpret_cast<const float*>(a.image + a.off_rowc);
+        const float* __restrict__ tab = reinterpret_cast<const float*>(a.image + a.off_tabP);
+        const float* __restrict__ xaT = reinterpret_cast<const float*>(a.image + a.off_extraA);
+        cj0 = rc[jc0];
+        cj1 = rc[jc1];
+#pragma unroll
+        for (int w = 0; w < WP; ++w) { aw0[w] = tab[(size_t)w * SP + jc0]; aw1[w] = tab[(size_t)w * SP + jc1]; }
+#pragma unroll
+        for (int k = 0; k < kMaxExtras; ++k) { xa0[k] = xaT[(size_t)k * SP + jc0]; xa1[k] = xaT[(size_t)k * SP + jc1]; }
+    }
+    const int role = wv - NPW;                 // 0 prefix scan, 1 suffix scan
+    const int blk = role == 1 ? 63 - lane : lane;
+    const int i0 = blk * EPL;
+    bool smask[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int i = i0 + e;
+        bool m = i >= S;
+#pragma unroll
+        for (int k = 0; k < kMaxExtras; ++k) m |= (k < nx && i == xcol[k]);
+        smask[e] = m;
+    }
+
+    // ---------------- frame 0
+    const float* __restrict__ lpi = reinterpret_cast<const float*>(a.image + a.off_logpi);
+    if (is_target) {
+        float d0 = -INFINITY, d1 = -INFINITY;
+        if (v0) { d0 = lpi[j0] + load_e<ET>(E + j0); hist[j0] = d0; }
+        if (v1) { d1 = lpi[j1] + load_e<ET>(E + j1); hist[j1] = d1; }
+        if (j1 < NP) { dl[j0] = d0; dl[j1] = d1; }
+    } else if (lane == 0) {
+        if (role == 0) Pv[0] = -INFINITY;
+        if (role == 1) Sv[NP] = -INFINITY;
+    }
+    // emission rows are fetched two frames ahead and consumed at the end of a frame (in-order vmcnt)
+    float ea0 = (v0 && Tb > 1) ? load_e<ET>(E + S + j0) : 0.f, ea1 = (v1 && Tb > 1) ? load_e<ET>(E + S + j1) : 0.f;
+    float eb0 = (v0 && Tb > 2) ? load_e<ET>(E + 2 * (size_t)S + j0) : 0.f, eb1 = (v1 && Tb > 2) ? load_e<ET>(E + 2 * (size_t)S + j1) : 0.f;
+#pragma unroll
+    for (int w = 0; w < WP; ++w) asm volatile("" ::"v"(aw0[w]), "v"(aw1[w]));
+#pragma unroll
+    for (int k = 0; k < kMaxExtras; ++k) asm volatile("" ::"v"(xa0[k]), "v"(xa1[k]));
+    asm volatile("" ::"v"(lo), "v"(cj0), "v"(cj1), "v"(ea0), "v"(ea1), "v"(eb0), "v"(eb1));
+    __syncthreads();
+
+    auto frame = [&](const int t, float& es0, float& es1) {
+        float m0 = -INFINITY, m1 = -INFINITY;
+        if (is_target) {
+            // ---- the two window maxima (read delta_{t-1}); two max3 chains per target
+            float n0 = -INFINITY, n1 = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < kMaxExtras; ++k)
+                if (k < nx) { const float dx = dl[xcol[k]]; m0 = fmaxf(m0, dx + xa0[k]); m1 = fmaxf(m1, dx + xa1[k]); }
+            if (!(dbg & 1)) {
+                float dw[WP];
+#pragma unroll
+                for (int w = 0; w < WP; ++w) dw[w] = dl[lo + w];
+#pragma unroll
+                for (int w = 0; w + 3 < WP; w += 4) {
+                    const f32x2 a0 = f32x2{dw[w], dw[w + 1]} + f32x2{aw0[w], aw0[w + 1]};
+                    const f32x2 a1 = f32x2{dw[w + 2], dw[w + 3]} + f32x2{aw0[w + 2], aw0[w + 3]};
+                    const f32x2 b0 = f32x2{dw[w], dw[w + 1]} + f32x2{aw1[w], aw1[w + 1]};
+                    const f32x2 b1 = f32x2{dw[w + 2], dw[w + 3]} + f32x2{aw1[w + 2], aw1[w + 3]};
+                    m0 = fmaxf(fmaxf(m0, a0.x), a0.y);
+                    n0 = fmaxf(fmaxf(n0, a1.x), a1.y);
+                    m1 = fmaxf(fmaxf(m1, b0.x), b0.y);
+                    n1 = fmaxf(fmaxf(n1, b1.x), b1.y);
+                }
+                if (WP % 4 == 2) {
+                    const f32x2 a0 = f32x2{dw[WP - 2], dw[WP - 1]} + f32x2{aw0[WP - 2], aw0[WP - 1]};
+                    const f32x2 b0 = f32x2{dw[WP - 2], dw[WP - 1]} + f32x2{aw1[WP - 2], aw1[WP - 1]};
+                    m0 = fmaxf(fmaxf(m0, a0.x), a0.y);
+                    m1 = fmaxf(fmaxf(m1, b0.x), b0.y);
+                }
+            }
+            m0 = fmaxf(m0, n0);
+            m1 = fmaxf(m1, n1);
+        } else if (!(dbg & 2)) {
+            float d[EPL], p[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) d[e] = dl[i0 + e];
+            float run = -INFINITY;
+            if (role == 0) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) { run = fmaxf(run, smask[e] ? -INFINITY : d[e]); p[e] = run; }
+                const float inc = wave_scan_max(run);
+                const float ex = wave_shift_up(inc, -INFINITY);                 // sources of all lower lanes
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) Pv[i0 + e + 1] = fmaxf(ex, p[e]);
+                // max of delta_{t-1} over the non-extra sources: bounds every row-constant candidate in the back-trace
+                if (lane == 63 && !(dbg & 8)) a.fmax[(size_t)song * T + (t - 1)] = inc;
+            } else {
+#pragma unroll
+                for (int e = EPL - 1; e >= 0; --e) { run = fmaxf(run, smask[e] ? -INFINITY : d[e]); p[e] = run; }
+                const float ex = wave_shift_up(wave_scan_max(run), -INFINITY);  // sources of all higher blocks
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) Sv[i0 + e] = fmaxf(ex, p[e]);
+            }
+        }
+        __syncthreads();
+
+        if (is_target && !(dbg & 4)) {
+            const float outside = fmaxf(Pv[lo], Sv[lo + WP]);
+            m0 = fmaxf(m0, outside + cj0);
+            m1 = fmaxf(m1, outside + cj1);
+            const float dn0 = m0 + es0, dn1 = m1 + es1;
+            if (j1 < NP) { dl[j0] = v0 ? dn0 : -INFINITY; dl[j1] = v1 ? dn1 : -INFINITY; }
+            if (!(dbg & 8)) {
+                float* __restrict__ hrow = hist + (size_t)t * SD;          // wave-uniform row bases
+                const ET* __restrict__ erow = E + (size_t)(t + 2) * S;
+                if (v0) hrow[j0] = dn0;
+                if (v1) hrow[j1] = dn1;
+                if (t + 2 < Tb) {
+                    if (v0) es0 = load_e<ET>(erow + j0);
+                    if (v1) es1 = load_e<ET>(erow + j1);
+                }
+            }
+        }
+        __syncthreads();
+    };
+    int t = 1;
+    for (; t + 1 < Tb; t += 2) {
+        frame(t, ea0, ea1);
+        frame(t + 1, eb0, eb1);
+    }
+    if (t < Tb) frame(t, ea0, ea1);
+
+    // terminal state: lowest-index argmax of delta_{T-1}; a target lane holds two adjacent states
+    {
+        VI x = vi_identity();
+        if (v0) x = VI{dl[j0], j0};
+        if (v1) x = op_fwd(x, VI{dl[j1], j1});
+        x = wave_scan<false>(x);
+        if (lane == 63) tot[wv] = x;
+        __syncthreads();
+        if (tid == 0) {
+            VI acc = vi_identity();
+            for (int b = 0; b < NPW; ++b) acc = op_fwd(acc, tot[b]);
+            if (acc.i == kBig) acc.i = 0;
+            a.last_state[song] = acc.i;
+            if (a.loglik) a.loglik[song] = acc.v;
+        }
     }
 }
 
@@ -805,7 +1006,13 @@ hipError_t launch_dense(const FwdArgs& a, int ns, bool f16, hipStream_t st) {
 template <int W, int NWT, typename ET>
 static hipError_t launch_banded_t(const FwdArgs& a, hipStream_t st) {
     constexpr int NP = NWT * 64;
-    const size_t lds = sizeof(float) * (NP + 2 * (NP + 1) + kMaxDenseRows) + sizeof(VI) * 16 + 16;
+    if (a.pair_ok && W <= 32 && (a.debug & 512)) {   // opt-in (VIT_DEBUG_FLAGS=512): measured slower, see DESIGN.md 4.1
+        constexpr int NPW = (NWT + 1) / 2;
+        const size_t lds = sizeof(float) * (NP + 2 * (NP + 1)) + sizeof(VI) * 16;
+        hipLaunchKernelGGL((banded_pair_forward_kernel<W, NWT, ET>), dim3((int)a.B), dim3((NPW + 2) * 64), lds, st, a);
+        return hipGetLastError();
+    }
+    const size_t lds = sizeof(float) * (4 * (NP + 16) + 2 * (NP + 1) + kMaxDenseRows) + sizeof(VI) * 16;
     // NWT + 2 waves put exactly two on each SIMD at S = 361 and let two workgroups share a CU.  Only a
     // plan with dense rows, run at one workgroup per CU, gets a separate wave for them (it would
     // otherwise lengthen the suffix wave, the critical one).

@@ -36,7 +36,8 @@ struct FwdArgs {
     int extras[kMaxExtras];
     float c0;
     int debug;              // timing-only ablation mask (VIT_DEBUG_FLAGS); 0 in production
-    size_t off_logpi, off_A4, off_lo, off_kind, off_tabA, off_extraA, off_denseA, off_rowc;
+    size_t off_logpi, off_A4, off_lo, off_kind, off_tabA, off_extraA, off_denseA, off_rowc, off_lo2, off_tabP;
+    int pair_ok;            // the plan proved pair windows: use the two-targets-per-lane kernel
 };
 
 struct BtArgs {

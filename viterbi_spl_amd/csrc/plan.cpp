@@ -115,6 +115,19 @@ BandedPlan analyze_banded(const float* A, int S) {
             if (bp.kind[j] == -1) all = bp.lo[j] == std::max(0, std::min(j - off, S - W));
         if (all) { bp.lo_affine = true; bp.lo_off = off; }
     }
+    // pair windows: two adjacent targets evaluated by one lane over a common window of W + 2 sources
+    {
+        const int WP = W + 2;
+        bp.lo2.assign(bp.SP / 2, 0);
+        bool ok = WP <= S && bp.n_dense == 0;
+        for (int p = 0; p < (S + 1) / 2 && ok; ++p) {
+            const int j0 = 2 * p, j1 = std::min(2 * p + 1, S - 1);
+            const int l = std::min(lo[j0], lo[j1]), h = std::max(hi[j0], hi[j1]);
+            if (h - l + 1 > WP) { ok = false; break; }
+            bp.lo2[p] = std::max(0, std::min(l, S - WP));
+        }
+        bp.pair_ok = ok;
+    }
     bp.ok = true;
     return bp;
 }
@@ -137,6 +150,8 @@ ImageLayout make_layout(int S, const BandedPlan& bp) {
     L.off_denseA = off; off = align256(off + sizeof(float) * kMaxDenseRows * L.SP);
     L.off_Arow = off;   off = align256(off + sizeof(float) * (size_t)S * L.SP);
     L.off_rowc = off;   off = align256(off + sizeof(float) * L.SP);
+    L.off_lo2 = off;    off = align256(off + sizeof(int32_t) * L.SP);
+    L.off_tabP = off;   off = align256(off + sizeof(float) * (size_t)(std::max(L.W, 1) + 2) * L.SP);
     L.bytes = off;
     return L;
 }
@@ -180,6 +195,14 @@ void fill_image(const float* A, const float* log_pi, const BandedPlan& bp, const
         for (int j = 0; j < S; ++j) xa[(size_t)k * SP + j] = A[(size_t)j * S + bp.extras[k]];
     for (int d = 0; d < bp.n_dense; ++d)
         for (int i = 0; i < S; ++i) da[(size_t)d * SP + i] = A[(size_t)bp.dense_rows[d] * S + i];
+    if (bp.pair_ok) {
+        int32_t* lo2 = reinterpret_cast<int32_t*>(image + L.off_lo2);
+        float* tp = reinterpret_cast<float*>(image + L.off_tabP);
+        for (int p = 0; p < SP / 2; ++p) lo2[p] = p < (int)bp.lo2.size() ? bp.lo2[p] : 0;
+        for (int w = 0; w < L.W + 2; ++w)
+            for (int j = 0; j < SP; ++j)
+                tp[(size_t)w * SP + j] = j < S ? A[(size_t)j * S + bp.lo2[j / 2] + w] : ninf;
+    }
 }
 
 }  // namespace vit

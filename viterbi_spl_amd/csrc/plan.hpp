@@ -40,6 +40,8 @@ struct BandedPlan {
     std::vector<int32_t> lo;  // [SP] first source of the evaluated window (lo + W <= S)
     std::vector<int32_t> kind;// [SP] -1 banded row, d >= 0 dense row d, -2 padding
     bool lo_affine = false;   // lo[j] == clamp(j - lo_off, 0, S - W) for every banded row
+    bool pair_ok = false;     // targets (2p, 2p+1) share one window [lo2[p], lo2[p]+W+2) that covers both
+    std::vector<int32_t> lo2; // [SP/2]
     int lo_off = 0;
 };
 
@@ -59,6 +61,8 @@ struct ImageLayout {
     size_t off_denseA = 0;   // float [4][SP]       denseA[d][i] = logA_T[dense_rows[d]][i]
     size_t off_Arow = 0;     // float [S][SP]       row-major copy (row j = into target j) for the back-trace
     size_t off_rowc = 0;     // float [SP]          row constants c_j
+    size_t off_lo2 = 0;      // int32 [SP/2]        pair windows (pair_ok)
+    size_t off_tabP = 0;     // float [W+2][SP]     tabP[w][j] = logA_T[j][lo2[j/2] + w]
     size_t bytes = 0;
 };
 
