@@ -133,6 +133,21 @@ int vit_backtrace(const vit_plan *plan, int64_t B, int64_t T, const int64_t *len
 int vit_voicing_map(const int32_t *states, int64_t n, int32_t n_bins, uint8_t *voiced, int32_t *bins,
                     vit_stream stream);
 
+/*
+ * Emission builders (the step upstream of the decoder): pitch logits -> log(p + tiny)
+ * observation log-probabilities in the [n_frames, n_bins+1] layout vit_decode() reads (unvoiced state last).
+ *   vit_obs_shaun   : Viterbi.observation_probs_fn, tonet/for_paper.py:1733-1778 -- logits [n_frames, n_bins];
+ *                     threshold_logit = log(th/(1-th)), offset = log(p/(1-p)), scale (:1697-1699, :1743-1745);
+ *                     spw = single-side peak width (5).
+ *   vit_obs_softmax : SoftMaxViterbi.observation_probs_fn, tonet/for_paper.py:1911-1944 -- logits
+ *                     [n_frames, n_bins+1] with column 0 = unvoiced; spw = 15.
+ * exp/log run on the GPU: probabilities agree with the reference to a few ulp, structural zeros are exact.
+ */
+int vit_obs_shaun(const float *logits, int64_t n_frames, int32_t n_bins, int32_t spw, double threshold_logit,
+                  double offset, double scale, float *logE, vit_stream stream);
+int vit_obs_softmax(const float *logits, int64_t n_frames, int32_t n_bins, int32_t spw, float *logE,
+                    vit_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,3 +26,16 @@ def sha(*arrays):
     for a in arrays:
         h.update(np.ascontiguousarray(a).tobytes())
     return h.hexdigest()
+
+
+def logits_case(seed, n_frames, n_bins):
+    """Seeded pitch logits for the emission-builder tests: weak noise floor (unvoiced frames), melody-like
+    bumps in two frames out of three, and some exactly tied values."""
+    rng = np.random.default_rng(seed)
+    x = rng.normal(-8.0, 1.5, (n_frames, n_bins)).astype(np.float32)
+    for f in range(n_frames):
+        if f % 3:
+            c = int(rng.integers(8, n_bins - 8))
+            x[f, c - 2:c + 3] += np.asarray([1.0, 3.0, 6.0, 3.0, 1.0], np.float32) * np.float32(rng.uniform(0.5, 2.5))
+    x[:, ::37] = np.round(x[:, ::37])
+    return x

@@ -82,3 +82,22 @@ def test_decode_refuses_cpu_tensors(golden):
     import viterbi_spl_amd as v
     with pytest.raises(ValueError):
         v.decode(torch.zeros(3, 321), golden["params"]["msnet321_logA_T"], golden["params"]["msnet321_log_pi"])
+
+
+def test_host_emission_builders_match_reference_goldens(golden, monkeypatch):
+    """The adapters' host-exact builders (used with exact_emissions=True) reproduce the reference bit for bit.
+    Constructed without a GPU: only the NumPy methods are exercised."""
+    import os
+    from tests.common import logits_case
+    from viterbi_spl_amd import reference_api as ra
+    og = np.load(os.path.join(os.path.dirname(__file__), "golden", "obs_goldens.npz"))
+    v = ra.Viterbi.__new__(ra.Viterbi)
+    v.num_freq_bins, v.single_side_peak_width, v.threshold = 360, 5, np.log(0.32 / (1. - 0.32))
+    s = ra.SoftMaxViterbi.__new__(ra.SoftMaxViterbi)
+    s.num_freq_bins, s.single_side_peak_width = 360, 15
+    for k in range(3):
+        seed, n = og[f"shaun{k}_seed"]
+        got = v.observation_probs_fn(logits_case(int(seed), int(n), 360))
+        assert got.flags["F_CONTIGUOUS"] and np.array_equal(np.ascontiguousarray(got.T), og[f"shaun{k}_probs"])
+        seed, n = og[f"softmax{k}_seed"]
+        assert np.array_equal(s.observation_probs_fn(logits_case(int(seed), int(n), 361)), og[f"softmax{k}_probs"])

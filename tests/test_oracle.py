@@ -84,3 +84,18 @@ def test_minus_inf_entries():
     a, la = vo.decode_c(logA_T, log_pi, logE)
     b, lb = vo.decode_numpy(logA_T, log_pi, logE)
     assert np.array_equal(a, b) and la == lb and np.isfinite(la)
+
+
+def test_observation_oracle_matches_reference_goldens():
+    """Emission builders: the NumPy restatement equals the reference's own outputs."""
+    import os
+    from oracle import observation_oracle as oo
+    from tests.common import logits_case
+    og = np.load(os.path.join(os.path.dirname(__file__), "golden", "obs_goldens.npz"))
+    for k in range(3):
+        seed, n = og[f"shaun{k}_seed"]
+        got = oo.shaun_observation_probs(logits_case(int(seed), int(n), 360))
+        assert np.array_equal(np.ascontiguousarray(got.T), og[f"shaun{k}_probs"])
+        seed, n = og[f"softmax{k}_seed"]
+        got = oo.softmax_observation_probs(logits_case(int(seed), int(n), 361))
+        assert np.array_equal(got, og[f"softmax{k}_probs"])

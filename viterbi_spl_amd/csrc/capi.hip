@@ -256,6 +256,21 @@ int vit_voicing_map(const int32_t* states, int64_t n, int32_t n_bins, uint8_t* v
     return e == hipSuccess ? VIT_OK : hip_fail(e);
 }
 
+int vit_obs_shaun(const float* logits, int64_t n_frames, int32_t n_bins, int32_t spw, double threshold_logit,
+                  double offset, double scale, float* logE, vit_stream stream) {
+    if (n_frames < 0 || n_bins < 2 || (n_frames > 0 && (!logits || !logE))) return VIT_EINVAL;
+    hipError_t e = vit::launch_obs_shaun(logits, n_frames, n_bins, spw, threshold_logit, offset, scale, logE, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue) return VIT_EUNSUPPORTED;
+    return e == hipSuccess ? VIT_OK : hip_fail(e);
+}
+
+int vit_obs_softmax(const float* logits, int64_t n_frames, int32_t n_bins, int32_t spw, float* logE, vit_stream stream) {
+    if (n_frames < 0 || n_bins < 2 || (n_frames > 0 && (!logits || !logE))) return VIT_EINVAL;
+    hipError_t e = vit::launch_obs_softmax(logits, n_frames, n_bins, spw, logE, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue) return VIT_EUNSUPPORTED;
+    return e == hipSuccess ? VIT_OK : hip_fail(e);
+}
+
 /* not part of the public header: DPP scan self-test used by tests/test_gpu_parity.py */
 int vit_debug_scan(const float* vals, int n_waves, int mode, float* out_v, int32_t* out_i, vit_stream stream) {
     if (!vals || !out_v || !out_i || n_waves < 1) return VIT_EINVAL;

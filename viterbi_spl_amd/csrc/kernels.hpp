@@ -69,6 +69,9 @@ hipError_t launch_voicing_map(const int32_t* states, int64_t n, int32_t n_bins, 
                               hipStream_t st);
 hipError_t launch_scan_selftest(const float* vals, int n_waves, int mode, float* out_v, int32_t* out_i,
                                 hipStream_t st);
+hipError_t launch_obs_shaun(const float* logits, int64_t n_frames, int U, int spw, double thr, double off, double sc,
+                            float* out, hipStream_t st);
+hipError_t launch_obs_softmax(const float* logits, int64_t n_frames, int U, int spw, float* out, hipStream_t st);
 int backtrace_tile_rows(int SD);
 constexpr int kBtWarm = 256;       // warm-up frames of a speculative chunk
 constexpr int kBtMaxChunks = 32;

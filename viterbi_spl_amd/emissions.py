@@ -1,0 +1,57 @@
+"""Emission builders on the GPU: pitch logits -> log observation probabilities.
+
+The reference builds the observation probabilities of a song with Python loops over its frames on the
+host (``Viterbi.observation_probs_fn`` tonet/for_paper.py:1733-1778, ``SoftMaxViterbi.observation_probs_fn``
+:1911-1944) and takes ``log(p + tiny)`` inside ``viterbi_librosa_fn``.  These functions do both steps in
+one kernel launch (``vit_obs_shaun`` / ``vit_obs_softmax``) and return the ``[..., T, n_bins+1]`` float32
+log-emission tensor that ``decode()`` consumes, so logits produced by an acoustic model on the GPU never
+visit the host (the ``.cpu().numpy()`` round trip at tonet/for_paper.py:2282).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib
+
+
+def _check(logits: torch.Tensor, last: int) -> torch.Tensor:
+    if not isinstance(logits, torch.Tensor) or logits.device.type != "cuda":
+        raise ValueError("logits must be a torch tensor on a ROCm GPU (there is no CPU path)")
+    if logits.dtype != torch.float32 or logits.dim() < 2 or logits.shape[-1] != last:
+        raise ValueError(f"logits must be float32 [..., frames, {last}]")
+    if not logits.is_contiguous():
+        raise ValueError("logits must be C-contiguous")
+    return logits
+
+
+def shaun_log_emissions(logits: torch.Tensor, voicing_threshold: float = 0.32, single_side_peak_width: int = 5,
+                        p: float = 0.8, scale: float = 2.0) -> torch.Tensor:
+    """``Viterbi.observation_probs_fn`` + log: logits ``[..., T, n_bins]`` -> log-emissions ``[..., T, n_bins+1]``."""
+    n_bins = logits.shape[-1]
+    logits = _check(logits, n_bins)
+    assert 0 < voicing_threshold < 1
+    out = torch.empty(logits.shape[:-1] + (n_bins + 1,), dtype=torch.float32, device=logits.device)
+    n = logits.numel() // n_bins
+    with torch.cuda.device(logits.device):
+        rc = _lib.load().vit_obs_shaun(logits.data_ptr(), n, n_bins, single_side_peak_width,
+                                       math.log(voicing_threshold / (1.0 - voicing_threshold)),
+                                       math.log(p / (1.0 - p)), scale, out.data_ptr(),
+                                       torch.cuda.current_stream(logits.device).cuda_stream)
+    _lib.check(rc, "vit_obs_shaun")
+    return out
+
+
+def softmax_log_emissions(logits: torch.Tensor, single_side_peak_width: int = 15) -> torch.Tensor:
+    """``SoftMaxViterbi.observation_probs_fn`` + log: logits ``[..., T, n_bins+1]`` (column 0 = unvoiced) ->
+    log-emissions ``[..., T, n_bins+1]`` with the unvoiced state last."""
+    S = logits.shape[-1]
+    logits = _check(logits, S)
+    out = torch.empty_like(logits)
+    n = logits.numel() // S
+    with torch.cuda.device(logits.device):
+        rc = _lib.load().vit_obs_softmax(logits.data_ptr(), n, S - 1, single_side_peak_width, out.data_ptr(),
+                                         torch.cuda.current_stream(logits.device).cuda_stream)
+    _lib.check(rc, "vit_obs_softmax")
+    return out

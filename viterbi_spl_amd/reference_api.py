@@ -131,9 +131,65 @@ class _PreparedViterbi:
         return voiced, bins
 
 
+def _find_peaks(frames_logits, spw):
+    """find_peaks_all_at_once_np_fn (tonet/for_paper.py:1714-1731): first maximum of the reflect-padded window."""
+    n_frames, n_bins = frames_logits.shape
+    padded = np.pad(frames_logits, [(0, 0), (spw, spw)], mode='reflect')
+    w = 2 * spw + 1
+    are_peaks = np.zeros([n_frames, n_bins], np.bool_)
+    for bin_idx in range(n_bins):
+        are_peaks[:, bin_idx] = np.argmax(padded[:, bin_idx:bin_idx + w], axis=1) == spw
+    return are_peaks
+
+
 class Viterbi(_PreparedViterbi):
-    """Family B (tonet/for_paper.py:1683-1870): emissions arrive as F-contiguous [S, T]
-    probabilities and are logged IN PLACE, as in the reference."""
+    """Family B (tonet/for_paper.py:1683-1870).  ``viterbi_librosa_fn`` takes F-contiguous [S, T]
+    probabilities and logs them IN PLACE, as in the reference.  ``__call__(logits)`` is the whole
+    post-processor (:1817-1831): emission builder -> decode -> (voiced, bins)."""
+
+    def __init__(self, transition_matrix, init_probs, voicing_threshold=0.32, num_freq_bins=None, device=None):
+        super().__init__(transition_matrix, init_probs, num_freq_bins, device)
+        assert 0 < voicing_threshold < 1
+        self.voicing_threshold = voicing_threshold
+        self.threshold = np.log(voicing_threshold / (1. - voicing_threshold))
+        self.single_side_peak_width = 5
+
+    @staticmethod
+    def expit(s):
+        if s > 0:
+            return 1. / (1. + np.exp(-s))
+        p = np.exp(s)
+        return p / (1. + p)
+
+    def observation_probs_fn(self, logits):
+        """Host NumPy builder, operation for operation the reference's (:1733-1778): bit-exact, slow."""
+        assert isinstance(logits, np.ndarray) and logits.dtype == np.float32
+        n_frames, n_freq_bins = logits.shape
+        assert n_freq_bins == self.num_freq_bins
+        offset = np.log(0.8 / (1. - 0.8))
+        scale = 2.
+        melodies_frames = np.zeros([n_freq_bins + 1, n_frames], np.float32, order='F')
+        are_peaks = _find_peaks(logits, self.single_side_peak_width)
+        for frame_idx in range(n_frames):
+            peak_indices = np.where(are_peaks[frame_idx])[0]
+            if len(peak_indices) == 0:
+                melodies_frames[-1, frame_idx] = 1
+                continue
+            peak_logits = logits[frame_idx][peak_indices]
+            g = peak_logits[np.argmax(peak_logits)]
+            if g >= self.threshold:
+                s = scale * (g - self.threshold) + offset
+            else:
+                s = scale * (g - self.threshold) - offset
+            p_voiced = Viterbi.expit(s)
+            peak_logits -= g
+            np.exp(peak_logits, out=peak_logits)
+            t = p_voiced / np.sum(peak_logits)
+            np.multiply(peak_logits, t, out=peak_logits)
+            melodies_frames[peak_indices, frame_idx] = peak_logits
+            melodies_frames[-1, frame_idx] = 1. - p_voiced
+        assert np.all(np.isclose(np.sum(melodies_frames, axis=0), 1))
+        return melodies_frames
 
     def viterbi_librosa_fn(self, probs_st):
         S = self.num_freq_bins + 1
@@ -145,15 +201,49 @@ class Viterbi(_PreparedViterbi):
         probs = np.require(probs_st.T, np.float32, ['C'])
         return _run(self.log_transition_matrix_T, self.log_ini_probs, probs, self._decoder)
 
-    def __call__(self, observation_probs_st):
-        """Decode + the (voiced, bins) post-map of Viterbi.__call__ (:1817-1831).  The
-        logits -> observation-probability builder (:1733-1778) is upstream of this path."""
-        return self._post(self.viterbi_librosa_fn(observation_probs_st))
+    def __call__(self, logits, exact_emissions=False):
+        """logits: [n_frames, n_bins] float32 (NumPy, or a torch tensor already on the GPU).
+        exact_emissions=True builds the observation probabilities on the host exactly like the reference
+        (bit-exact end to end); the default builds them on the GPU (vit_obs_shaun: same decisions, exp/log
+        within a few ulp) so that GPU-resident logits never visit the host."""
+        if exact_emissions:
+            lg = logits.detach().cpu().numpy() if isinstance(logits, torch.Tensor) else logits
+            return self._post(self.viterbi_librosa_fn(self.observation_probs_fn(lg)))
+        from .emissions import shaun_log_emissions
+        lg = logits if isinstance(logits, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(logits, np.float32))
+        lg = lg.to(self._decoder.device).contiguous()
+        logE = shaun_log_emissions(lg, self.voicing_threshold, self.single_side_peak_width)
+        states, _ = self._decoder.decode(logE, out_dtype=torch.int64)
+        return self._post(states.cpu().numpy())
 
 
 class SoftMaxViterbi(_PreparedViterbi):
     """Family C (tonet/for_paper.py:1873-2037): C-contiguous [T, S] probabilities (values may
-    exceed 1 for scaled likelihoods), logged IN PLACE."""
+    exceed 1 for scaled likelihoods), logged IN PLACE.  ``__call__(logits)`` as above."""
+
+    def __init__(self, transition_matrix, init_probs, num_freq_bins=None, device=None):
+        super().__init__(transition_matrix, init_probs, num_freq_bins, device)
+        self.single_side_peak_width = 15
+
+    def observation_probs_fn(self, logits):
+        """Host NumPy builder following :1911-1944 (unvoiced logit first, rolled to the last state)."""
+        assert isinstance(logits, np.ndarray) and logits.dtype == np.float32 and logits.ndim == 2
+        assert logits.shape[1] == self.num_freq_bins + 1 and logits.flags['C_CONTIGUOUS']
+        n_frames, n_bins = len(logits), self.num_freq_bins
+        prob_ts = np.zeros([n_frames, 1 + n_bins], np.float32)
+        are_peaks_ts = np.zeros([n_frames, n_bins + 1], np.bool_)
+        are_peaks_ts[:, 0] = True
+        are_peaks_ts[:, 1:] = _find_peaks(logits[:, 1:], self.single_side_peak_width)
+        for frame_idx, are_peaks in enumerate(are_peaks_ts):
+            peak_indices = np.where(are_peaks)[0]
+            if len(peak_indices) == 1:
+                prob_ts[frame_idx, 0] = 1
+                continue
+            peak_logits = logits[frame_idx, peak_indices]
+            peak_logits = np.exp(peak_logits - np.max(peak_logits))
+            prob_ts[frame_idx, peak_indices] = peak_logits / np.sum(peak_logits)
+        assert np.allclose(np.sum(prob_ts, axis=1), 1)
+        return np.roll(prob_ts, shift=-1, axis=1)
 
     def viterbi_librosa_fn(self, probs_ts):
         S = self.num_freq_bins + 1
@@ -165,5 +255,13 @@ class SoftMaxViterbi(_PreparedViterbi):
         np.log(probs_ts, out=probs_ts)
         return _run(self.log_transition_matrix_T, self.log_ini_probs, probs_ts, self._decoder)
 
-    def __call__(self, observation_probs_ts):
-        return self._post(self.viterbi_librosa_fn(observation_probs_ts))
+    def __call__(self, logits, exact_emissions=False):
+        if exact_emissions:
+            lg = logits.detach().cpu().numpy() if isinstance(logits, torch.Tensor) else logits
+            return self._post(self.viterbi_librosa_fn(self.observation_probs_fn(np.ascontiguousarray(lg))))
+        from .emissions import softmax_log_emissions
+        lg = logits if isinstance(logits, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(logits, np.float32))
+        lg = lg.to(self._decoder.device).contiguous()
+        logE = softmax_log_emissions(lg, self.single_side_peak_width)
+        states, _ = self._decoder.decode(logE, out_dtype=torch.int64)
+        return self._post(states.cpu().numpy())
