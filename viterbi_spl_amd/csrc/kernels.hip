@@ -364,9 +364,9 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
         if (is_target) {
             // ---- window max (reads delta_{t-1}); four independent max3 chains
             float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+            float xd[kMaxExtras];
 #pragma unroll
-            for (int k = 0; k < kMaxExtras; ++k)
-                if (k < nx) m0 = fmaxf(m0, dl[xcol[k]] + xa[k]);
+            for (int k = 0; k < kMaxExtras; ++k) xd[k] = k < nx ? dl[xcol[k]] : -INFINITY;
             if (!(dbg & 1)) {
                 // copy (lo & 3), entry (lo & ~3): delta[lo .. lo+W) as W/4 aligned 16-byte reads
                 const f32x4* __restrict__ win = reinterpret_cast<const f32x4*>(dl + (lo & 3) * DC + (lo & ~3));
@@ -384,6 +384,9 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
                     m3 = fmaxf(fmaxf(m3, c3_.x), c3_.y);
                 }
             }
+            // extra columns are consumed after the window so that their LDS read shares the window's wait
+#pragma unroll
+            for (int k = 0; k < kMaxExtras; ++k) m1 = fmaxf(m1, xd[k] + xa[k]);
             m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
         } else if (!(dbg & 2)) {
             float d[EPL];
@@ -799,18 +802,18 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
                 }
             }
             bool done = false;
-            if (fast_ok && (kd == -1 || (a.debug & 64))) {
+            if (fast_ok && kd == -1) {
                 // ---- common case: only the window + extra-column candidates of target jj
                 const int src = lane < W ? lo + lane : xsrc;
                 float v = -INFINITY;
                 if (lane < WX) v = row[src] + tabX[lane * SP + jj];
                 const float m = wave_max_all(v);
                 const float mf = fm[r] + rowcL[jj];   // fl(max_i delta_t[i] + c_jj) bounds every row-constant candidate
-                if (mf < m || (a.debug & 64)) {  // no floor candidate can tie or win
+                if (mf < m) {                    // no row-constant candidate can tie or win
                     const unsigned long long mk = __ballot(v == m);
                     unsigned idx = 0x7fffffffu;
-                    if (mk & wmask) idx = lo + __builtin_ctzll(mk & wmask);
-                    unsigned long long mx = W >= 64 ? 0ull : (mk >> W);
+                    if (mk & wmask) idx = lo + __builtin_ctzll(mk & wmask);   // window lanes ascend with the source index
+                    unsigned long long mx = W >= 64 ? 0ull : (mk >> W);       // extra-column lanes: arbitrary indices
                     while (mx) {
                         const unsigned c = a.extras[__builtin_ctzll(mx) & (kMaxExtras - 1)];
                         idx = c < idx ? c : idx;
@@ -820,7 +823,7 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
                     done = true;
                 }
             }
-            if (!done && !(a.debug & 128)) {
+            if (!done) {
                 // ---- full evaluation: every source (c0 floor / window / extras / dense row / matrix row)
                 float d[EPL], vf[EPL];
 #pragma unroll

@@ -73,7 +73,7 @@ hipError_t launch_obs_shaun(const float* logits, int64_t n_frames, int U, int sp
                             float* out, hipStream_t st);
 hipError_t launch_obs_softmax(const float* logits, int64_t n_frames, int U, int spw, float* out, hipStream_t st);
 int backtrace_tile_rows(int SD);
-constexpr int kBtWarm = 256;       // warm-up frames of a speculative chunk
+constexpr int kBtWarm = 128;       // warm-up frames of a speculative chunk (survivor paths coalesce within tens of frames)
 constexpr int kBtMaxChunks = 32;
 int backtrace_chunks(int64_t B, int T);
 
