@@ -245,7 +245,10 @@ __global__ void __launch_bounds__(dense_max_threads(NS)) dense_forward_kernel(Fw
 // the frame time is set by the VALU instruction count of the busiest SIMD plus the two barriers.
 // Two workgroup barriers per frame; emission rows are fetched two frames ahead.
 // ---------------------------------------------------------------------------------------
-template <int W, int NWT, bool DW, typename ET>
+// DBG = true adds the timing-experiment hooks (ablation mask, cycle stamps); the production instantiation has none.
+// NXT >= 0 specialises for exactly NXT extra columns and no dense rows (the reference's matrices: NXT = 1);
+// NXT < 0 is the generic form (run-time counts).  Every untaken branch costs an issue slot per frame.
+template <int W, int NWT, bool DW, bool DBG, int NXT, typename ET>
 __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kernel(FwdArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NP = NWT * 64;
@@ -271,8 +274,10 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
     const int Tb = song_length(a.lengths, song, T);
     const ET* __restrict__ E = reinterpret_cast<const ET*>(a.logE) + (size_t)song * T * S;
     float* __restrict__ hist = a.hist + (size_t)song * T * SD;
-    const int nx = a.n_extras, nd = a.n_dense;
-    const int dbg = a.debug;
+    constexpr bool GEN = NXT < 0;
+    constexpr int NXL = GEN ? kMaxExtras : NXT;            // extra columns the loops are unrolled for
+    const int nx = GEN ? a.n_extras : NXT, nd = GEN ? a.n_dense : 0;
+    const int dbg = DBG ? a.debug : 0;
 
     // ---------------- per-role setup
     const bool is_target = wv < NWT;
@@ -364,9 +369,9 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
         if (is_target) {
             // ---- window max (reads delta_{t-1}); four independent max3 chains
             float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
-            float xd[kMaxExtras];
+            float xd[NXL > 0 ? NXL : 1];
 #pragma unroll
-            for (int k = 0; k < kMaxExtras; ++k) xd[k] = k < nx ? dl[xcol[k]] : -INFINITY;
+            for (int k = 0; k < NXL; ++k) xd[k] = (!GEN || k < nx) ? dl[xcol[k]] : -INFINITY;
             if (!(dbg & 1)) {
                 // copy (lo & 3), entry (lo & ~3): delta[lo .. lo+W) as W/4 aligned 16-byte reads
                 const f32x4* __restrict__ win = reinterpret_cast<const f32x4*>(dl + (lo & 3) * DC + (lo & ~3));
@@ -386,7 +391,7 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
             }
             // extra columns are consumed after the window so that their LDS read shares the window's wait
 #pragma unroll
-            for (int k = 0; k < kMaxExtras; ++k) m1 = fmaxf(m1, xd[k] + xa[k]);
+            for (int k = 0; k < NXL; ++k) m1 = fmaxf(m1, xd[k] + xa[k]);
             m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
         } else if (!(dbg & 2)) {
             float d[EPL];
@@ -419,7 +424,7 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
 #pragma unroll
                     for (int e = 0; e < EPL; ++e) Sv[i0 + e] = fmaxf(ex, p[e]);
                 }
-                if (role == kDenseRole) {
+                if (GEN && role == kDenseRole) {
 #pragma unroll
                     for (int dr = 0; dr < kMaxDenseRows; ++dr) {
                         if (dr < nd) {
@@ -439,8 +444,10 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
 
         if (is_target && !(dbg & 4)) {
             m = fmaxf(m, fmaxf(Pv[lo], Sv[lo + W]) + cj);
-            const float dres = Dv[kind >= 0 ? kind : 0];
-            if (kind >= 0) m = dres;
+            if (GEN) {
+                const float dres = Dv[kind >= 0 ? kind : 0];
+                if (kind >= 0) m = dres;
+            }
             if (tvalid) {
                 const float dn = m + e_slot;
 #pragma unroll
@@ -1020,9 +1027,15 @@ static hipError_t launch_banded_t(const FwdArgs& a, hipStream_t st) {
     // plan with dense rows, run at one workgroup per CU, gets a separate wave for them (it would
     // otherwise lengthen the suffix wave, the critical one).
     if (a.n_dense > 0 && a.B <= 256)
-        hipLaunchKernelGGL((banded_forward_kernel<W, NWT, true, ET>), dim3((int)a.B), dim3((NWT + 3) * 64), lds, st, a);
+        hipLaunchKernelGGL((banded_forward_kernel<W, NWT, true, false, -1, ET>), dim3((int)a.B), dim3((NWT + 3) * 64), lds, st, a);
+    else if (a.debug)
+        hipLaunchKernelGGL((banded_forward_kernel<W, NWT, false, true, -1, ET>), dim3((int)a.B), dim3((NWT + 2) * 64), lds, st, a);
+    else if (W == 32 && a.n_dense == 0 && a.n_extras == 1)   // the reference's matrices: band + unvoiced column
+        hipLaunchKernelGGL((banded_forward_kernel<W, NWT, false, false, (W == 32 ? 1 : -1), ET>), dim3((int)a.B), dim3((NWT + 2) * 64), lds, st, a);
+    else if (W == 32 && a.n_dense == 0 && a.n_extras == 0)
+        hipLaunchKernelGGL((banded_forward_kernel<W, NWT, false, false, (W == 32 ? 0 : -1), ET>), dim3((int)a.B), dim3((NWT + 2) * 64), lds, st, a);
     else
-        hipLaunchKernelGGL((banded_forward_kernel<W, NWT, false, ET>), dim3((int)a.B), dim3((NWT + 2) * 64), lds, st, a);
+        hipLaunchKernelGGL((banded_forward_kernel<W, NWT, false, false, -1, ET>), dim3((int)a.B), dim3((NWT + 2) * 64), lds, st, a);
     return hipGetLastError();
 }
 
