@@ -15,7 +15,7 @@ for _ in range(2):
     dec.decode_into(E, st, ll, algo="banded", phase="forward")
 torch.cuda.synchronize()
 os.environ["VIT_DEBUG_FLAGS"] = "0"
-SD = 364
+SD = (S + 4) // 4 * 4
 off = ((B * T * SD * 4 + 255) // 256) * 256
 base = (dec._ws.data_ptr() + 255) & ~255
 ws = dec._ws[base - dec._ws.data_ptr():]

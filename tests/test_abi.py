@@ -53,7 +53,7 @@ def test_plan_create_query_is_host_only(lib, golden):
     assert info.n_extras == 1 and info.extras[0] == 360
     assert lib.vit_plan_image_bytes(plan) > 361 * 361 * 4
     ws = lib.vit_workspace_bytes(plan, 128, 30000)
-    assert ws >= 128 * 30000 * 364 * 4   # float32 delta history, rows padded to 16 bytes
+    assert ws >= 128 * 30000 * 364 * 4   # float32 delta history, rows padded to 16 bytes (+ >= 1 pad column)
     # decode before upload is refused, not executed
     dummy = ctypes.c_void_p(256 * 1024)
     rc = lib.vit_decode(plan, dummy, 0, 1, 10, None, dummy, ws, dummy, None, 0, None)

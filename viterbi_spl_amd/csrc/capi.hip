@@ -23,7 +23,7 @@ namespace {
 thread_local int g_last_hip_error = 0;
 
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
-inline int hist_stride(int S) { return (S + 3) / 4 * 4; }
+inline int hist_stride(int S) { return (S + 4) / 4 * 4; }   // rows 16-byte aligned with at least one pad column
 
 int hip_fail(hipError_t e) {
     g_last_hip_error = (int)e;

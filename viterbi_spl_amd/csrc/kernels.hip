@@ -283,6 +283,8 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
     const bool is_target = wv < NWT;
     const int j = tid;
     const bool tvalid = is_target && j < S;
+    const int jst = j < S ? j : S;                         // idle lanes store into pad column S of the history row (SD > S always)
+    const int jld = j < S ? j : S - 1;
     const int jc = j < SP ? j : 0;
     int lo = 0, kind = -2;
     float cj = 0.f;
@@ -448,15 +450,19 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
                 const float dres = Dv[kind >= 0 ? kind : 0];
                 if (kind >= 0) m = dres;
             }
-            if (tvalid) {
-                const float dn = m + e_slot;
+            {
+                // Every target lane stores and prefetches unconditionally (idle lanes: a pad column of the
+                // history row / the last valid emission) so that the in-order vmcnt of the next use is exact
+                // -- a conditional would make the compiler wait for the previous frame's store as well.
+                const float dn = tvalid ? m + e_slot : -INFINITY;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) dl[c * DC + j - c] = dn;
                 if (!(dbg & 8)) {
                     float* __restrict__ hrow = hist + (size_t)t * SD;          // wave-uniform row bases:
-                    const ET* __restrict__ erow = E + (size_t)(t + 2) * S;      // scalar base + lane offset
-                    hrow[j] = dn;
-                    if (t + 2 < Tb) e_slot = load_e<ET>(erow + j);
+                    const int tn = t + 2 < Tb ? t + 2 : Tb - 1;                 // scalar base + lane offset
+                    const ET* __restrict__ erow = E + (size_t)tn * S;
+                    hrow[jst] = dn;
+                    e_slot = load_e<ET>(erow + jld);
                 }
             }
         }

@@ -26,7 +26,7 @@ struct FwdArgs {
     const uint8_t* image;   // device plan image
     const void* logE;       // [B,T,S] f32 or f16
     const int64_t* lengths; // [B] or null
-    float* hist;            // [B,T,SD] delta history (the reference's T1), SD = ceil(S/4)*4
+    float* hist;            // [B,T,SD] delta history (the reference's T1), SD = (S/4+1)*4 (>= 1 pad column)
     float* fmax;            // [B,T] banded plan: fmax[t] = max_i delta_t[i] over the non-extra sources
     int32_t* last_state;    // [B]
     float* loglik;          // [B] or null
