@@ -170,7 +170,7 @@ def main():
                 bt_traffic = json.load(open(tf)).get(key, {}).get("backtrace", {}).get("hbm_bytes_per_launch")
             except Exception:
                 bt_traffic = None
-        SD = (S + 4) // 4 * 4
+        SD = (S + 5) // 4 * 4
         out = {
             "metric": "Viterbi Mframes/s at S=361 T=30k; achieved HBM GB/s vs peak",
             "value": value, "unit": "Mframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -101,7 +101,7 @@ size_t vit_plan_image_bytes(const vit_plan *plan);
 int vit_plan_upload(vit_plan *plan, void *device_image, size_t bytes, vit_stream stream);
 
 /* Bytes of device workspace vit_decode() needs for a [B,T,S] batch (float32 delta history
- * [B,T,(S/4+1)*4] + per-frame floor maxima [B,T] + per-song terminals).  256-byte aligned
+ * [B,T,SD], SD = ceil((S+2)/4)*4, whose pad column S holds the per-frame maximum + per-song terminals).  256-byte aligned
  * base required. */
 size_t vit_workspace_bytes(const vit_plan *plan, int64_t B, int64_t T);
 

@@ -15,11 +15,11 @@ for _ in range(2):
     dec.decode_into(E, st, ll, algo="banded", phase="forward")
 torch.cuda.synchronize()
 os.environ["VIT_DEBUG_FLAGS"] = "0"
-SD = (S + 4) // 4 * 4
+SD = (S + 5) // 4 * 4
 off = ((B * T * SD * 4 + 255) // 256) * 256
 base = (dec._ws.data_ptr() + 255) & ~255
 ws = dec._ws[base - dec._ws.data_ptr():]
-fm = ws[off: off + B * T * 4].view(torch.float32).view(B, T)
+fm = ws[off: off + B * 64 * 4].view(torch.float32).view(B, 64)
 names = ["work1", "barB", "merge", "barA"]
 for w, role in [(0, "target0"), (3, "target3"), (5, "target5"), (6, "prefix"), (7, "suffix"), (8, "dense")]:
     v = fm[:, 4 * w: 4 * w + 4].mean(dim=0).tolist()

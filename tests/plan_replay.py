@@ -46,6 +46,7 @@ class HostPlan:
         self.dense_rows = [int(x) for x in info[11:11 + self.n_dense]]
         self.S4 = int(info[15]) & 0xFFFF
         self.pair_ok = bool(int(info[15]) & 0x10000)
+        self.floor_ok = bool(int(info[15]) & 0x20000)
         self.c0 = np.float32(c0[0])
         SP, S4 = self.SP, self.S4
 
@@ -62,7 +63,7 @@ class HostPlan:
         self.rowc = sec(9, np.float32, SP)
 
 
-def replay_banded(plan: HostPlan, logE):
+def replay_banded(plan: HostPlan, logE, floor=False):
     """Follows the GPU kernels step by step on the host.
 
     Forward (banded_forward_kernel): value-only; per target the max of the W window sums, of
@@ -71,8 +72,11 @@ def replay_banded(plan: HostPlan, logE):
     Back-trace (lazy_backtrace_kernel): for the path state j at t+1 rebuild every candidate
     fl(delta_t[i] + logA_T[j][i]) from the plan tables and take the LOWEST index attaining the max;
     the fast path (window + extras only) is taken when fl(max_i delta_t[i] + c_j) < window max.
+    floor=True follows banded_floor_forward_kernel instead: the out-of-window term is fl(M + c_j) with M the
+    max of the raw delta over ALL non-extra sources (needs plan.floor_ok).
     Returns (states int64[T], loglik, final delta[S])."""
     assert plan.ok
+    assert plan.floor_ok or not floor
     S, W = plan.S, plan.W
     logE = np.ascontiguousarray(logE, np.float32)
     T = logE.shape[0]
@@ -95,7 +99,10 @@ def replay_banded(plan: HostPlan, logE):
         sv = np.concatenate([np.maximum.accumulate(raw[::-1])[::-1], [ninf]])  # sv[q] = max raw[q:]
         dmax[t - 1] = pv[S]
         m = np.max((delta[win_idx] + tab).astype(np.float32), axis=1)
-        outside = (np.maximum(pv[lo], sv[lo + W]) + rowc).astype(np.float32)
+        if floor:
+            outside = (pv[S] + rowc).astype(np.float32)
+        else:
+            outside = (np.maximum(pv[lo], sv[lo + W]) + rowc).astype(np.float32)
         m = np.maximum(m, outside)
         for k, x in enumerate(plan.extras):
             m = np.maximum(m, (delta[x] + plan.extraA[k, :S]).astype(np.float32))

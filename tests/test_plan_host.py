@@ -57,6 +57,10 @@ def test_banded_replay_is_bit_exact(golden, pname, kind, T, seed):
     ref, rl, rdelta = vo.decode_c(A, pi, E, return_delta=True)
     assert np.array_equal(st, ref)
     assert delta.tobytes() == rdelta.tobytes() and np.float32(ll) == np.float32(rl)
+    # the reference's matrices also qualify for the one-maximum ("floor-max") form of the forward kernel
+    assert plan.floor_ok
+    st2, ll2, delta2 = replay_banded(plan, E, floor=True)
+    assert np.array_equal(st2, ref) and delta2.tobytes() == rdelta.tobytes()
 
 
 def _banded_matrix(S, half, rng, extras=(), dense_rows=(), floor=-50.0, quant=4):
@@ -89,6 +93,35 @@ def test_random_banded_structures_with_ties(seed):
     ref, rl, rdelta = vo.decode_c(A, pi, E, return_delta=True)
     assert np.array_equal(st, ref)
     assert delta.tobytes() == rdelta.tobytes()
+    # floor-max form: only proven when no in-window entry is below the row constant and there are no dense rows
+    assert plan.floor_ok == (plan.n_dense == 0 and _window_ge_floor(A, plan))
+    if plan.floor_ok:
+        st2, _, delta2 = replay_banded(plan, E, floor=True)
+        assert np.array_equal(st2, ref) and delta2.tobytes() == rdelta.tobytes()
+
+
+def _window_ge_floor(A, plan):
+    S, W = plan.S, plan.W
+    for j in range(S):
+        for i in range(plan.lo[j], plan.lo[j] + W):
+            if i not in plan.extras and not A[j, i] >= plan.rowc[j]:
+                return False
+    return True
+
+
+def test_floor_form_is_refused_when_a_window_entry_is_below_the_row_constant():
+    """The one-maximum form would be WRONG here (an in-window source could win through the row constant):
+    the plan must not offer it, and the scan form must stay exact."""
+    rng = np.random.default_rng(5)
+    S = 96
+    A = _banded_matrix(S, 4, rng, floor=-2.0, quant=1)     # window entries down to -39, floor -2
+    pi = np.zeros(S, np.float32)
+    plan = HostPlan(A, pi)
+    assert plan.ok and not plan.floor_ok
+    E = -(rng.integers(0, 4, (50, S))).astype(np.float32)
+    st, _, delta = replay_banded(plan, E)
+    ref, _, rdelta = vo.decode_c(A, pi, E, return_delta=True)
+    assert np.array_equal(st, ref) and delta.tobytes() == rdelta.tobytes()
 
 
 def test_banded_with_minus_inf_floor():

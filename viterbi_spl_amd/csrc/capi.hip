@@ -23,7 +23,7 @@ namespace {
 thread_local int g_last_hip_error = 0;
 
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
-inline int hist_stride(int S) { return (S + 4) / 4 * 4; }   // rows 16-byte aligned with at least one pad column
+inline int hist_stride(int S) { return (S + 5) / 4 * 4; }   // rows 16-byte aligned, at least two pad columns (frame max, scratch)
 
 int hip_fail(hipError_t e) {
     g_last_hip_error = (int)e;
@@ -38,7 +38,7 @@ WsLayout ws_layout(int S, int64_t B, int64_t T) {
     WsLayout w;
     w.off_hist = 0;
     w.off_fmax = align256((size_t)B * (size_t)T * hist_stride(S) * sizeof(float));
-    w.off_last = w.off_fmax + align256((size_t)B * (size_t)T * sizeof(float));
+    w.off_last = w.off_fmax + align256((size_t)B * 64 * sizeof(float));   // timing-experiment scratch
     w.off_entry = w.off_last + align256((size_t)B * sizeof(int32_t));
     w.bytes = w.off_entry + align256((size_t)B * vit::kBtMaxChunks * sizeof(int32_t));
     return w;
@@ -105,6 +105,7 @@ int vit_plan_query(const vit_plan* plan, vit_plan_info* info) {
     info->max_window = plan->bp.max_window;
     info->group_window = plan->bp.W;
     info->reserved[0] = plan->bp.n_dense;
+    info->reserved[1] = plan->bp.ok && plan->bp.floor_ok ? 1 : 0;
     info->consts[0] = plan->bp.c0;
     for (int k = 0; k < vit::kMaxExtras; ++k) info->extras[k] = k < plan->bp.n_extras ? plan->bp.extras[k] : -1;
     return VIT_OK;
@@ -179,6 +180,7 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
     a.off_lo2 = plan->L.off_lo2;
     a.off_tabP = plan->L.off_tabP;
     a.pair_ok = plan->bp.ok && plan->bp.pair_ok ? 1 : 0;
+    a.floor_ok = plan->bp.ok && plan->bp.floor_ok ? 1 : 0;
 
     hipError_t e;
     if (algo == VIT_ALGO_BANDED) {
@@ -203,7 +205,6 @@ int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* len
     vit::BtArgs b{};
     b.image = plan->dev_image;
     b.hist = reinterpret_cast<const float*>(ws + w.off_hist);
-    b.fmax = reinterpret_cast<const float*>(ws + w.off_fmax);
     b.last_state = reinterpret_cast<const int32_t*>(ws + w.off_last);
     b.lengths = lengths;
     b.states = states;

@@ -283,7 +283,7 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
     const bool is_target = wv < NWT;
     const int j = tid;
     const bool tvalid = is_target && j < S;
-    const int jst = j < S ? j : S;                         // idle lanes store into pad column S of the history row (SD > S always)
+    const int jst = j < S ? j : S + 1;                     // idle lanes store into pad column S+1 of the history row (SD >= S+2 always)
     const int jld = j < S ? j : S - 1;
     const int jc = j < SP ? j : 0;
     int lo = 0, kind = -2;
@@ -412,7 +412,7 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) Pv[i0 + e + 1] = fmaxf(ex, p[e]);
                 // max of delta_{t-1} over the non-extra sources: bounds every row-constant candidate in the back-trace
-                if (lane == 63 && !(dbg & 8)) a.fmax[(size_t)song * T + (t - 1)] = inc;
+                if (lane == 63 && !(dbg & 8)) hist[(size_t)(t - 1) * SD + S] = inc;   // pad column S of row t-1
             } else {
                 if (role == 1) {
                     float p[EPL];
@@ -484,12 +484,181 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
 
     terminal_argmax(is_target ? dl[j] : -INFINITY, j, tvalid, tot, NWT + (DW ? 3 : 2), a.last_state, a.loglik, song);
     if ((dbg & 256) && lane == 0 && Tb > 1) {   // per-wave phase averages -> fmax[song][4*wave .. 4*wave+3]
-        float* o = a.fmax + (size_t)song * T + 4 * wv;
+        float* o = a.fmax + (size_t)song * 64 + 4 * wv;
         const float n = (float)(Tb - 1);
         o[0] = (float)ph0 / n; o[1] = (float)ph1 / n; o[2] = (float)ph2 / n; o[3] = (float)ph3 / n;
     }
     if ((dbg & 48) && tid == 0 && a.loglik) {  // timing experiments only: cycles (16) or 100 MHz ticks (32) per frame
         const unsigned long long d = (dbg & 16) ? __builtin_amdgcn_s_memtime() - clk0 : __builtin_amdgcn_s_memrealtime() - rt0;
+        a.loglik[song] = (float)d / (float)(Tb > 1 ? Tb - 1 : 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Banded forward kernel, "floor-max" form (plan.floor_ok): one song per workgroup, value-only, ONE barrier
+// and no scan waves per frame.
+//
+// The plan proved that no in-window entry of a banded row is below the row constant c_j.  Let M be the max of
+// the RAW delta_{t-1} over all non-extra sources, attained at i*.  If i* is outside the window of target j,
+// fl(M + c_j) IS the out-of-window term.  If i* is inside, fl(M + c_j) <= fl(delta_i* + logA_T[j][i*]) (rounding
+// is monotone and logA_T[j][i*] >= c_j), which the window max already contains, and every out-of-window term is
+// <= fl(M + c_j) -- so in both cases
+//   m_j = max( window max, fl(M + c_j), extra-column terms )
+// is the value the dense recursion computes, bit for bit.  M is one number per frame: every wave reduces the
+// delta values it has just produced (six DPP max steps) and publishes one float; after the frame's only barrier
+// every lane combines the NWT wave maxima.  delta is double-buffered in LDS (four shifted copies each, see
+// banded_forward_kernel), so nothing a wave reads in frame t is written before the barrier that ends frame t.
+// M (= the back-trace's bound on every row-constant candidate) is stored in pad column S of the history row.
+// ---------------------------------------------------------------------------------------
+template <int W, int NWT, int NXT, int PF, typename ET, int ABL = 0>
+__global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int NP = NWT * 64;
+    constexpr int DC = NP + 16;                   // copy stride (see banded_forward_kernel)
+    constexpr int BUF = 4 * DC;                   // floats per delta buffer
+    constexpr int NWM = (NWT + 3) / 4 * 4;        // wave maxima per buffer, padded to whole float4s with -inf
+    float* dls = reinterpret_cast<float*>(smem);  // [2][4][DC]
+    float* wm = dls + 2 * BUF;                    // [2][NWM]
+    float* dump = wm + 2 * NWM;                   // [64 + NWM] per-lane dump slots (lanes that do not own a wave max)
+    VI* tot = reinterpret_cast<VI*>(dump + 64 + NWM);
+    const int S = a.S, SP = a.SP, T = a.T, SD = a.SD;
+    constexpr bool GEN = NXT < 0;
+    constexpr int NXL = GEN ? kMaxExtras : NXT;
+    const int nx = GEN ? a.n_extras : NXT;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int song = blockIdx.x;
+    const int Tb = song_length(a.lengths, song, T);
+    const ET* __restrict__ E = reinterpret_cast<const ET*>(a.logE) + (size_t)song * T * S;
+    float* __restrict__ hist = a.hist + (size_t)song * T * SD;
+
+    // ---------------- per-lane constants.  Idle lanes (j >= S) carry -inf tables: their delta stays -inf.
+    const int j = tid;
+    const bool tvalid = j < S;
+    const int jc = tvalid ? j : 0;
+    const int jld = tvalid ? j : S - 1;                                   // emission column an idle lane (harmlessly) loads
+    // history store of frame t, relative to row t-1: own column of row t | lane S: M into pad column S of row t-1
+    // | other idle lanes: pad column S+1 of row t (never read)
+    const unsigned hoff = tvalid ? (unsigned)(SD + j) : (j == S ? (unsigned)S : (unsigned)(SD + S + 1));
+    const bool is_fm = j == S;
+    const int lo = reinterpret_cast<const int32_t*>(a.image + a.off_lo)[jc];
+    const float cj = tvalid ? reinterpret_cast<const float*>(a.image + a.off_rowc)[jc] : -INFINITY;
+    float aw[W];
+    float xa[NXL > 0 ? NXL : 1];
+    int xcol[NXL > 0 ? NXL : 1];
+    bool is_x = false;                                                    // this lane's state is an extra column: not part of M
+    {
+        const float* __restrict__ tab = reinterpret_cast<const float*>(a.image + a.off_tabA);
+        const float* __restrict__ xaT = reinterpret_cast<const float*>(a.image + a.off_extraA);
+#pragma unroll
+        for (int w = 0; w < W; ++w) aw[w] = tvalid ? tab[(size_t)w * SP + jc] : -INFINITY;
+#pragma unroll
+        for (int k = 0; k < NXL; ++k) {
+            xcol[k] = k < nx ? a.extras[k] : 0;
+            xa[k] = (tvalid && k < nx) ? xaT[(size_t)k * SP + jc] : -INFINITY;
+            is_x |= (k < nx && j == xcol[k]);
+        }
+    }
+    const int lov = tvalid ? lo : 0;
+    const float* rp = dls + 4 + (lov & 3) * DC + (lov & ~3);              // window start in the copy that aligns it
+    float* wp = dls + 4 + j;                                              // own entry of copy 0 (copy c: + c*DC - c)
+    float* wmp = lane == 63 ? wm + wv : dump + lane;                      // lane 63 ends up with the wave maximum
+
+    for (int k = tid; k < 2 * BUF + 2 * NWM; k += NWT * 64) dls[k] = -INFINITY;
+    __syncthreads();
+
+    // produce(): publish a new delta value -- four shifted copies and the wave's share of M -- into buffer WB
+    auto produce = [&](const float dn, const int WB) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wp[WB * BUF + c * DC - c] = dn;
+        const float inc = ABL == 1 ? dn : wave_scan_max((NXL > 0 && is_x) ? -INFINITY : dn);
+        wmp[WB * NWM] = inc;
+    };
+
+    // ---------------- frame 0
+    {
+        const float d0 = tvalid ? reinterpret_cast<const float*>(a.image + a.off_logpi)[j] + load_e<ET>(E + j) : -INFINITY;
+        if (tvalid) hist[j] = d0;
+        produce(d0, 0);
+    }
+    // Emission rows are fetched PF frames ahead (PF even): a global load takes ~2 us under load, several frame times,
+    // and the s_waitcnt before a frame's "+ e" must not be what paces the recursion.
+    float er[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) er[k] = load_e<ET>(E + (size_t)(1 + k < Tb ? 1 + k : Tb - 1) * S + jld);
+#pragma unroll
+    for (int w = 0; w < W; ++w) asm volatile("" ::"v"(aw[w]));
+#pragma unroll
+    for (int k = 0; k < NXL; ++k) asm volatile("" ::"v"(xa[k]));
+    asm volatile("" ::"v"(cj));
+    __syncthreads();
+
+    auto frame = [&](const int t, float& e_slot, const int RB) {
+        const int WB = RB ^ 1;
+        // ---- everything this frame reads from LDS: the window, the extra columns, the wave maxima
+        const f32x4* __restrict__ win = reinterpret_cast<const f32x4*>(rp + RB * BUF);
+        float xd[NXL > 0 ? NXL : 1];
+#pragma unroll
+        for (int k = 0; k < NXL; ++k) xd[k] = dls[4 + RB * BUF + xcol[k]];
+        // the NWT wave maxima: whole float4s, plus one float2 when NWT % 4 is 2 or 3 (slots >= NWT hold -inf)
+        f32x4 wq[NWT / 4 > 0 ? NWT / 4 : 1];
+        f32x2 wr = f32x2{-INFINITY, -INFINITY};
+        float wl = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < NWT / 4; ++q) wq[q] = reinterpret_cast<const f32x4*>(wm + RB * NWM)[q];
+        if (NWT % 4 >= 2) wr = *reinterpret_cast<const f32x2*>(wm + RB * NWM + (NWT / 4) * 4);
+        if (NWT % 4 == 1 || NWT % 4 == 3) wl = wm[RB * NWM + NWT - 1];
+        float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+#pragma unroll
+        for (int w = 0; w + 7 < (ABL == 2 ? 8 : W); w += 8) {
+            const f32x4 da = win[w / 4], db = win[w / 4 + 1];
+            const f32x2 c0_ = f32x2{da.x, da.y} + f32x2{aw[w + 0], aw[w + 1]};
+            const f32x2 c1_ = f32x2{da.z, da.w} + f32x2{aw[w + 2], aw[w + 3]};
+            const f32x2 c2_ = f32x2{db.x, db.y} + f32x2{aw[w + 4], aw[w + 5]};
+            const f32x2 c3_ = f32x2{db.z, db.w} + f32x2{aw[w + 6], aw[w + 7]};
+            m0 = fmaxf(fmaxf(m0, c0_.x), c0_.y);
+            m1 = fmaxf(fmaxf(m1, c1_.x), c1_.y);
+            m2 = fmaxf(fmaxf(m2, c2_.x), c2_.y);
+            m3 = fmaxf(fmaxf(m3, c3_.x), c3_.y);
+        }
+        // M = max of delta_{t-1} over the non-extra sources
+        float M = wl;
+        if (NWT % 4 >= 2) M = fmaxf(fmaxf(M, wr.x), wr.y);
+#pragma unroll
+        for (int q = 0; q < NWT / 4; ++q) M = fmaxf(fmaxf(fmaxf(M, wq[q].x), wq[q].y), fmaxf(wq[q].z, wq[q].w));
+        m0 = fmaxf(m0, M + cj);
+#pragma unroll
+        for (int k = 0; k < NXL; ++k) m1 = fmaxf(m1, xd[k] + xa[k]);
+        const float dn = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)) + e_slot;
+        produce(dn, WB);
+        // unconditional store + prefetch: exact in-order vmcnt accounting (see banded_forward_kernel)
+        float* __restrict__ hb = hist + (size_t)(t - 1) * SD;
+        const int tn = t + PF < Tb ? t + PF : Tb - 1;
+        const ET* __restrict__ erow = E + (size_t)tn * S;
+        if (ABL != 3) {
+            hb[hoff] = is_fm ? M : dn;
+            e_slot = load_e<ET>(erow + jld);
+        }
+        if (ABL != 4) __syncthreads();
+    };
+    const bool probe = (a.debug & 48) != 0;
+    const unsigned long long clk0 = probe ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long rt0 = probe ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    int t = 1;
+    for (; t + PF - 1 < Tb; t += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) frame(t + k, er[k], k & 1);
+    }
+#pragma unroll
+    for (int k = 0; k < PF - 1; ++k)
+        if (t + k < Tb) frame(t + k, er[k], k & 1);
+
+    const int fb = (Tb - 1) & 1;                                          // buffer holding delta_{Tb-1}
+    terminal_argmax(tvalid ? dls[4 + fb * BUF + j] : -INFINITY, j, tvalid, tot, NWT, a.last_state, a.loglik, song);
+    if (probe && tid == 0 && a.loglik) {  // timing experiments only: cycles (16) or 100 MHz ticks (32) per frame
+        const unsigned long long d = (a.debug & 16) ? __builtin_amdgcn_s_memtime() - clk0 : __builtin_amdgcn_s_memrealtime() - rt0;
         a.loglik[song] = (float)d / (float)(Tb > 1 ? Tb - 1 : 1);
     }
 }
@@ -629,7 +798,7 @@ __global__ void __launch_bounds__(((NWT + 1) / 2 + 2) * 64) banded_pair_forward_
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) Pv[i0 + e + 1] = fmaxf(ex, p[e]);
                 // max of delta_{t-1} over the non-extra sources: bounds every row-constant candidate in the back-trace
-                if (lane == 63 && !(dbg & 8)) a.fmax[(size_t)song * T + (t - 1)] = inc;
+                if (lane == 63 && !(dbg & 8)) hist[(size_t)(t - 1) * SD + S] = inc;   // pad column S of row t-1
             } else {
 #pragma unroll
                 for (int e = EPL - 1; e >= 0; --e) { run = fmaxf(run, smask[e] ? -INFINITY : d[e]); p[e] = run; }
@@ -714,12 +883,11 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
     const int nx = a.n_extras, nd = a.n_dense;
     const int WX = W + nx;                  // window candidates + extra-column candidates, one per lane
     const bool fast_ok = banded && a.have_fmax && WX <= 64;
-    // LDS: [tile per wave: kBtVec*64 float4][out per wave: 64 ints][fmax per wave: 64 floats]
+    // LDS: [tile per wave: kBtVec*64 float4][out per wave: 64 ints]
     //      [tables: lo, kind, tabX = window rows then extra rows]
     f32x4* tiles = reinterpret_cast<f32x4*>(smem);
     int32_t* outs = reinterpret_cast<int32_t*>(tiles + kBtWaves * kBtVec * 64);
-    float* fms = reinterpret_cast<float*>(outs + kBtWaves * 64);
-    int32_t* loL = reinterpret_cast<int32_t*>(fms + kBtWaves * 64);
+    int32_t* loL = outs + kBtWaves * 64;
     int32_t* kindL = loL + SP;
     float* rowcL = reinterpret_cast<float*>(kindL + SP);  // [SP] row constants
     float* tabX = rowcL + SP;                             // [(W + kMaxExtras)][SP]
@@ -746,11 +914,9 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
     const int Tb = song_length(a.lengths, song, T);
     int32_t* __restrict__ states = a.states + (size_t)song * T;
     const float* __restrict__ hist = a.hist + (size_t)song * T * SD;
-    const float* __restrict__ fmaxg = a.fmax + (size_t)song * T;
     const float* __restrict__ Arow = reinterpret_cast<const float*>(a.image + a.off_Arow);
     float* tile = reinterpret_cast<float*>(tiles + wv * kBtVec * 64);
     int32_t* out = outs + wv * 64;
-    float* fm = fms + wv * 64;
 
 
     // loop invariants
@@ -779,23 +945,19 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
     const int rv = SD / 4;  // float4 per row
     auto chase = [&](int top, const int bottom, int cur, const bool write) -> int {
     f32x4 stage[kBtVec];
-    float fstage = 0.f;
     if (top >= bottom) {
         const int first = top - K + 1 > bottom ? top - K + 1 : bottom;
         bt_fetch(stage, reinterpret_cast<const f32x4*>(hist + (size_t)first * SD), (top - first + 1) * rv, lane);
-        if (fast_ok) fstage = fmaxg[first + (lane < top - first + 1 ? lane : 0)];
     }
     while (top >= bottom) {
         const int first = top - K + 1 > bottom ? top - K + 1 : bottom;
         const int rows = top - first + 1;
 #pragma unroll
         for (int v = 0; v < kBtVec; ++v) reinterpret_cast<f32x4*>(tile)[lane + v * 64] = stage[v];
-        fm[lane] = fstage;
         const int ntop = first - 1;
         if (ntop >= bottom) {
             const int nfirst = ntop - K + 1 > bottom ? ntop - K + 1 : bottom;
             bt_fetch(stage, reinterpret_cast<const f32x4*>(hist + (size_t)nfirst * SD), (ntop - nfirst + 1) * rv, lane);
-            if (fast_ok) fstage = fmaxg[nfirst + (lane < ntop - nfirst + 1 ? lane : 0)];
         }
         for (int r = rows - 1; r >= 0; --r) {
             const float* row = tile + r * SD;   // delta_t, t = first + r; decides the state at frame t
@@ -821,7 +983,7 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
                 float v = -INFINITY;
                 if (lane < WX) v = row[src] + tabX[lane * SP + jj];
                 const float m = wave_max_all(v);
-                const float mf = fm[r] + rowcL[jj];   // fl(max_i delta_t[i] + c_jj) bounds every row-constant candidate
+                const float mf = row[S] + rowcL[jj];  // pad column S = max_i delta_t[i] (non-extra): fl(. + c_jj) bounds every row-constant candidate
                 if (mf < m) {                    // no row-constant candidate can tie or win
                     const unsigned long long mk = __ballot(v == m);
                     unsigned idx = 0x7fffffffu;
@@ -1028,6 +1190,28 @@ static hipError_t launch_banded_t(const FwdArgs& a, hipStream_t st) {
         hipLaunchKernelGGL((banded_pair_forward_kernel<W, NWT, ET>), dim3((int)a.B), dim3((NPW + 2) * 64), lds, st, a);
         return hipGetLastError();
     }
+    if (a.floor_ok && a.S < NP && !(a.debug & ~(48 | 16384 | 32768 | 0xf0000))) {   // one barrier, no scan waves (lane S stores the frame maximum: needs S < NP)
+        constexpr int NWM = (NWT + 3) / 4 * 4;
+        const size_t ldsf = sizeof(float) * (8 * (NP + 16) + 2 * NWM + 64 + NWM) + sizeof(VI) * 16;
+        if (W == 32 && a.n_extras == 1) {
+            if (a.debug & 0x10000)
+                hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, (W == 32 ? 1 : -1), 4, ET, 1>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
+            else if (a.debug & 0x20000)
+                hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, (W == 32 ? 1 : -1), 4, ET, 2>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
+            else if (a.debug & 0x40000)
+                hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, (W == 32 ? 1 : -1), 4, ET, 3>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
+            else if (a.debug & 0x80000)
+                hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, (W == 32 ? 1 : -1), 4, ET, 4>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
+            else if (a.debug & 16384)
+                hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, (W == 32 ? 1 : -1), 2, ET>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
+            else if (a.debug & 32768)
+                hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, (W == 32 ? 1 : -1), 8, ET>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
+            else
+                hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, (W == 32 ? 1 : -1), 4, ET>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
+        } else
+            hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, -1, 4, ET>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
+        return hipGetLastError();
+    }
     const size_t lds = sizeof(float) * (4 * (NP + 16) + 2 * (NP + 1) + kMaxDenseRows) + sizeof(VI) * 16;
     // NWT + 2 waves put exactly two on each SIMD at S = 361 and let two workgroups share a CU.  Only a
     // plan with dense rows, run at one workgroup per CU, gets a separate wave for them (it would
@@ -1088,7 +1272,7 @@ int backtrace_tile_rows(int SD) {
 
 template <int NWT>
 static hipError_t launch_bt_t(const BtArgs& a, hipStream_t st) {
-    size_t lds = sizeof(f32x4) * kBtWaves * kBtVec * 64 + sizeof(int32_t) * kBtWaves * 64 * 2;
+    size_t lds = sizeof(f32x4) * kBtWaves * kBtVec * 64 + sizeof(int32_t) * kBtWaves * 64;
     if (a.banded) lds += sizeof(int32_t) * 2 * a.SP + sizeof(float) * (1 + kMaxExtras + a.W) * a.SP;
     const long long waves0 = (long long)a.B * a.chunks;
     hipLaunchKernelGGL((lazy_backtrace_kernel<NWT, 0>), dim3((int)((waves0 + kBtWaves - 1) / kBtWaves)), dim3(kBtWaves * 64),

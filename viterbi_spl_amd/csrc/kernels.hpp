@@ -26,8 +26,9 @@ struct FwdArgs {
     const uint8_t* image;   // device plan image
     const void* logE;       // [B,T,S] f32 or f16
     const int64_t* lengths; // [B] or null
-    float* hist;            // [B,T,SD] delta history (the reference's T1), SD = (S/4+1)*4 (>= 1 pad column)
-    float* fmax;            // [B,T] banded plan: fmax[t] = max_i delta_t[i] over the non-extra sources
+    float* hist;            // [B,T,SD] delta history (the reference's T1), SD = ceil((S+2)/4)*4: columns [0,S) = delta_t,
+                            // column S = max_i delta_t[i] over the non-extra sources (banded kernels), S+1.. = scratch
+    float* fmax;            // [B,64] scratch for the timing experiments (phase stamps)
     int32_t* last_state;    // [B]
     float* loglik;          // [B] or null
     int64_t B;
@@ -38,12 +39,12 @@ struct FwdArgs {
     int debug;              // timing-only ablation mask (VIT_DEBUG_FLAGS); 0 in production
     size_t off_logpi, off_A4, off_lo, off_kind, off_tabA, off_extraA, off_denseA, off_rowc, off_lo2, off_tabP;
     int pair_ok;            // the plan proved pair windows: use the two-targets-per-lane kernel
+    int floor_ok;           // the plan proved the one-maximum form (banded_floor_forward_kernel)
 };
 
 struct BtArgs {
     const uint8_t* image;
     const float* hist;      // [B,T,SD]
-    const float* fmax;      // [B,T] (banded plan)
     const int32_t* last_state;
     const int64_t* lengths;
     int32_t* states;        // [B,T]
@@ -52,7 +53,7 @@ struct BtArgs {
     int T, S, SP, SD, W, K;
     int chunks, warm;       // time-parallel back-trace: chunks per song, warm-up frames
     int banded;             // 1: row structure (window / c0 / extras / dense rows) proven by the plan
-    int have_fmax;          // the forward pass was the banded kernel (it fills fmax)
+    int have_fmax;          // the forward pass was a banded kernel (it fills pad column S of the history rows)
     int debug;              // timing-only ablation mask (VIT_DEBUG_FLAGS); 0 in production
     int lo_affine, lo_off;  // lo[j] == clamp(j - lo_off, 0, S - W)
     int dense_rows[kMaxDenseRows];

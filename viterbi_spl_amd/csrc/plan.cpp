@@ -128,6 +128,20 @@ BandedPlan analyze_banded(const float* A, int S) {
         }
         bp.pair_ok = ok;
     }
+    // "floor-max" form: if no in-window entry of a banded row is below the row constant, the window term already
+    // dominates fl(delta_i + c_j) for every in-window source i (rounding is monotone), so the out-of-window maximum
+    // may be taken over ALL non-extra sources -- one number per frame instead of a prefix and a suffix scan.
+    {
+        bool ok = bp.n_dense == 0;
+        for (int j = 0; j < S && ok; ++j) {
+            const float cj = bp.rowc[j];
+            for (int w = 0; w < W && ok; ++w) {
+                const int i = bp.lo[j] + w;
+                if (!is_extra(i) && !(A[(size_t)j * S + i] >= cj)) ok = false;
+            }
+        }
+        bp.floor_ok = ok;
+    }
     bp.ok = true;
     return bp;
 }

@@ -40,6 +40,8 @@ struct BandedPlan {
     std::vector<int32_t> lo;  // [SP] first source of the evaluated window (lo + W <= S)
     std::vector<int32_t> kind;// [SP] -1 banded row, d >= 0 dense row d, -2 padding
     bool lo_affine = false;   // lo[j] == clamp(j - lo_off, 0, S - W) for every banded row
+    bool floor_ok = false;    // every non-extra window entry of every banded row is >= that row's constant, and no dense rows:
+                              // then max_{i outside window} fl(delta_i + c_j) can be replaced by fl(max_{all non-extra i} delta_i + c_j)
     bool pair_ok = false;     // targets (2p, 2p+1) share one window [lo2[p], lo2[p]+W+2) that covers both
     std::vector<int32_t> lo2; // [SP/2]
     int lo_off = 0;

@@ -29,7 +29,7 @@ void vph_info(const vph_plan* p, int* info, float* c0) {
     info[0] = p->bp.ok; info[1] = p->bp.S; info[2] = p->bp.SP; info[3] = p->bp.W;
     info[4] = p->bp.n_extras; info[5] = p->bp.n_dense; info[6] = p->bp.max_window;
     for (int k = 0; k < 4; ++k) { info[7 + k] = p->bp.extras[k]; info[11 + k] = p->bp.dense_rows[k]; }
-    info[15] = p->L.S4 | (p->bp.pair_ok ? 0x10000 : 0);
+    info[15] = p->L.S4 | (p->bp.pair_ok ? 0x10000 : 0) | (p->bp.floor_ok ? 0x20000 : 0);
     *c0 = p->bp.c0;
 }
 // offsets[0..9]: logpi, A4, lo, kind, tabA, extraA, denseA, total bytes, Arow, rowc
