@@ -510,7 +510,7 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
 // banded_forward_kernel), so nothing a wave reads in frame t is written before the barrier that ends frame t.
 // M (= the back-trace's bound on every row-constant candidate) is stored in pad column S of the history row.
 // ---------------------------------------------------------------------------------------
-template <int W, int NWT, int NXT, int PF, typename ET, int ABL = 0>
+template <int W, int NWT, int NXT, int PF, typename ET>
 __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NP = NWT * 64;
@@ -573,7 +573,7 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
     auto produce = [&](const float dn, const int WB) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) wp[WB * BUF + c * DC - c] = dn;
-        const float inc = ABL == 1 ? dn : wave_scan_max((NXL > 0 && is_x) ? -INFINITY : dn);
+        const float inc = wave_scan_max((NXL > 0 && is_x) ? -INFINITY : dn);
         wmp[WB * NWM] = inc;
     };
 
@@ -612,7 +612,7 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
         if (NWT % 4 == 1 || NWT % 4 == 3) wl = wm[RB * NWM + NWT - 1];
         float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
 #pragma unroll
-        for (int w = 0; w + 7 < (ABL == 2 ? 8 : W); w += 8) {
+        for (int w = 0; w + 7 < W; w += 8) {
             const f32x4 da = win[w / 4], db = win[w / 4 + 1];
             const f32x2 c0_ = f32x2{da.x, da.y} + f32x2{aw[w + 0], aw[w + 1]};
             const f32x2 c1_ = f32x2{da.z, da.w} + f32x2{aw[w + 2], aw[w + 3]};
@@ -637,11 +637,9 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
         float* __restrict__ hb = hist + (size_t)(t - 1) * SD;
         const int tn = t + PF < Tb ? t + PF : Tb - 1;
         const ET* __restrict__ erow = E + (size_t)tn * S;
-        if (ABL != 3) {
-            hb[hoff] = is_fm ? M : dn;
-            e_slot = load_e<ET>(erow + jld);
-        }
-        if (ABL != 4) __syncthreads();
+        hb[hoff] = is_fm ? M : dn;
+        e_slot = load_e<ET>(erow + jld);
+        __syncthreads();
     };
     const bool probe = (a.debug & 48) != 0;
     const unsigned long long clk0 = probe ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -854,15 +852,17 @@ __global__ void __launch_bounds__(((NWT + 1) / 2 + 2) * 64) banded_pair_forward_
 }
 
 // ---------------------------------------------------------------------------------------
-// Lazy back-trace: one wave per song (kBtWaves songs per workgroup share the LDS tables).
-// For frame t (descending) and the path state j at t+1 it rebuilds the candidates of target j
-//   fl(delta_t[i] + logA_T[j][i])   for every source i
-// from the stored delta row (window / c0 floor / extra columns / dense row, or the full matrix
-// row for unstructured matrices), takes the max over the wave and picks the LOWEST index
-// attaining it (v_cmp_eq lane masks + s_ff1).  Delta rows are staged through LDS in tiles of K
-// frames; the next tile is in flight in registers while the current one is chased.
+// Banded back-trace, lean form: banded plan without dense rows whose forward pass left the frame maximum in
+// pad column S of every history row.  Same decisions as lazy_backtrace_kernel (below), organised for the
+// dependent chain of one step -- state -> two LDS reads -> add -> wave max -> compare -> lowest matching lane:
+//   * lane l < W holds window candidate l, lanes W.. hold the extra-column candidates, and lane 63 forms
+//     fl(max_i delta_t[i] + c_j) with the same two reads (pad column S of the row, the row-constant table), so the
+//     bound that admits the fast path costs no extra instructions;
+//   * the candidate table is stored per target (tabX[j][.] contiguous: conflict-free), every index is
+//     wave-uniform scalar arithmetic, decided states are collected in a register and written once per tile;
+//   * the full evaluation (a row-constant candidate may tie or win) is a separate, rarely taken block.
+// One wave per (song, chunk) in MODE 0 / per song in MODE 1, blockDim/64 waves per workgroup share the tables.
 // ---------------------------------------------------------------------------------------
-constexpr int kBtWaves = 4;
 constexpr int kBtVec = 12;  // float4 per lane per tile: K * SD <= 12 * 256 floats
 
 __device__ __forceinline__ void bt_fetch(f32x4 (&stage)[kBtVec], const f32x4* __restrict__ rows, int nvec, int lane) {
@@ -872,6 +872,224 @@ __device__ __forceinline__ void bt_fetch(f32x4 (&stage)[kBtVec], const f32x4* __
         stage[v] = rows[idx < nvec ? idx : nvec - 1];  // clamped: always inside the tile
     }
 }
+
+template <int NWT, bool AFF, int MODE>
+__global__ void __launch_bounds__(512) banded_backtrace_kernel(BtArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int EPL = NWT;               // sources per lane in the full evaluation, strided: i = e*64 + lane
+    constexpr int TF = kBtVec * 256;       // floats per wave tile
+    const int S = a.S, SP = a.SP, SD = a.SD, T = a.T, W = a.W, K = a.K;
+    const int nx = a.n_extras;
+    const int WX = W + nx;                 // candidates held by lanes 0 .. WX-1 (WX <= 62)
+    const int WXS = W + kMaxExtras;
+    const int nwaves = blockDim.x >> 6;
+    const float* L = reinterpret_cast<const float*>(smem);          // all LDS indices below are float indices into L
+    float* tiles = reinterpret_cast<float*>(smem);                  // [nwaves][TF]
+    float* rowcL = tiles + nwaves * TF;                             // [SP]
+    int32_t* loL = reinterpret_cast<int32_t*>(rowcL + SP);          // [SP]
+    float* tabX = reinterpret_cast<float*>(loL + SP);               // [SP][WXS]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {
+        const int32_t* gl = reinterpret_cast<const int32_t*>(a.image + a.off_lo);
+        const float* gx = reinterpret_cast<const float*>(a.image + a.off_extraA);
+        const float* gt = reinterpret_cast<const float*>(a.image + a.off_tabA);
+        const float* gc = reinterpret_cast<const float*>(a.image + a.off_rowc);
+        const int nthr = blockDim.x;
+        for (int k = tid; k < SP; k += nthr) { loL[k] = gl[k]; rowcL[k] = gc[k]; }
+        for (int k = tid; k < W * SP; k += nthr) tabX[(k % SP) * WXS + k / SP] = gt[k];
+        for (int k = tid; k < kMaxExtras * SP; k += nthr) tabX[(k % SP) * WXS + W + k / SP] = gx[k];
+    }
+    __syncthreads();
+
+    const int C = a.chunks;
+    const int gw = blockIdx.x * nwaves + wv;            // global wave index
+    const int song = MODE == 0 ? gw / C : gw;
+    const int chunk = MODE == 0 ? gw % C : 0;
+    if (song >= a.B) return;
+    const int Tb = song_length(a.lengths, song, T);
+    int32_t* __restrict__ states = a.states + (size_t)song * T;
+    const float* __restrict__ hist = a.hist + (size_t)song * T * SD;
+    float* tile = tiles + wv * TF;
+    const int tile_off = wv * TF;
+
+    // ---- per-lane constants
+    const bool isw = lane < W;
+    const int xs = (lane >= W && lane < WX) ? a.extras[(lane - W) & (kMaxExtras - 1)] : 0;
+    const int pb = lane == 63 ? S : (isw ? lane : xs);                       // row entry read by this lane (window lanes: + lo)
+    const int tb = lane == 63 ? (int)(rowcL - tiles) : (int)(tabX - tiles) + (lane < WXS ? lane : WXS - 1);
+    const int ts = lane == 63 ? 1 : WXS;                                    // table index = tb + state * ts
+    const bool cand = lane < WX;
+    const unsigned long long wmask = (1ull << W) - 1ull;                    // W <= 32 here
+    int ic[EPL];
+    bool isx[EPL], inS[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int i = e * 64 + lane;
+        ic[e] = i < SD ? i : SD - 1;
+        inS[e] = i < S;
+        bool x = i >= S;
+#pragma unroll
+        for (int k = 0; k < kMaxExtras; ++k) x |= (k < nx && i == a.extras[k]);
+        isx[e] = x;
+    }
+    const int rv = SD / 4;  // float4 per row
+
+    // chase(top, bottom, cur, write): decide the states of frames top .. bottom (descending) from the delta rows
+    // top .. bottom, starting from state `cur` at frame top+1; a tile holds rows [first, top].
+    auto chase = [&](int top, const int bottom, int cur, const bool write) -> int {
+        f32x4 stage[kBtVec];
+        if (top >= bottom) {
+            const int first = top - K + 1 > bottom ? top - K + 1 : bottom;
+            bt_fetch(stage, reinterpret_cast<const f32x4*>(hist + (size_t)first * SD), (top - first + 1) * rv, lane);
+        }
+        while (top >= bottom) {
+            const int first = top - K + 1 > bottom ? top - K + 1 : bottom;
+            const int rows = top - first + 1;
+#pragma unroll
+            for (int v = 0; v < kBtVec; ++v) reinterpret_cast<f32x4*>(tile)[lane + v * 64] = stage[v];
+            const int ntop = first - 1;
+            if (ntop >= bottom) {
+                const int nfirst = ntop - K + 1 > bottom ? ntop - K + 1 : bottom;
+                bt_fetch(stage, reinterpret_cast<const f32x4*>(hist + (size_t)nfirst * SD), (ntop - nfirst + 1) * rv, lane);
+            }
+            int outv = 0;
+            int row_off = __builtin_amdgcn_readfirstlane(tile_off + (rows - 1) * SD);
+            for (int r = __builtin_amdgcn_readfirstlane(rows - 1); r >= 0; --r, row_off -= SD) {
+                // row r of the tile = delta_t, t = first + r: decides the state at frame t from the state `cur` at t+1
+                cur = __builtin_amdgcn_readfirstlane(cur);
+                int lo;
+                if (AFF) {
+                    lo = cur - a.lo_off;
+                    lo = lo < 0 ? 0 : (lo > S - W ? S - W : lo);
+                } else {
+                    lo = __builtin_amdgcn_readfirstlane(loL[cur]);
+                }
+                const float dv = L[row_off + pb + (isw ? lo : 0)];
+                const float av = L[tb + (int)__umul24((unsigned)cur, (unsigned)ts)];
+                const float vall = dv + av;
+                // lane 63: fl(max_i delta_t[i] + c_cur), the bound on every row-constant candidate
+                const float mf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vall), 63));
+                const float v = cand ? vall : -INFINITY;
+                const float m = wave_max_all(v);
+                unsigned idx = 0x7fffffffu;
+                if (mf < m) {
+                    // ---- common case: no row-constant candidate can tie or win
+                    const unsigned long long mk = __ballot(v == m);
+                    const unsigned long long mw = mk & wmask;
+                    if (mw) idx = lo + __builtin_ctzll(mw);                  // window lanes ascend with the source index
+                    unsigned mx = (unsigned)(mk >> W) & ((1u << kMaxExtras) - 1u);
+                    while (mx) {                                             // extra-column lanes: arbitrary indices
+                        const unsigned c = __builtin_amdgcn_readlane(pb, W + __builtin_ctz(mx));
+                        idx = c < idx ? c : idx;
+                        mx &= mx - 1;
+                    }
+                } else {
+                    // ---- full evaluation: every source outside the window / extras contributes fl(delta_t[i] + c_cur)
+                    const float cj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(av), 63));
+                    float vf[EPL];
+                    float m2 = -INFINITY;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) {
+                        const int i = e * 64 + lane;
+                        const float d = L[row_off + ic[e]];
+                        const bool excl = isx[e] || (unsigned)(i - lo) < (unsigned)W;
+                        vf[e] = excl ? -INFINITY : d + cj;
+                        m2 = fmaxf(m2, vf[e]);
+                    }
+                    const float mm = fmaxf(m, wave_max_all(m2));
+                    // lowest index among the candidates equal to the max (an all -inf frame resolves to index 0
+                    // like np.argmax: every in-range source then matches)
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) {
+                        const unsigned long long mk = __ballot(vf[e] == mm && inS[e]);
+                        if (mk) { const unsigned c = e * 64 + __builtin_ctzll(mk); idx = c < idx ? c : idx; }
+                    }
+                    const unsigned long long mk = __ballot(v == mm && cand);
+                    const unsigned long long mw = mk & wmask;
+                    if (mw) { const unsigned c = lo + __builtin_ctzll(mw); idx = c < idx ? c : idx; }
+                    unsigned mx = (unsigned)(mk >> W) & ((1u << kMaxExtras) - 1u);
+                    while (mx) {
+                        const unsigned c = __builtin_amdgcn_readlane(pb, W + __builtin_ctz(mx));
+                        idx = c < idx ? c : idx;
+                        mx &= mx - 1;
+                    }
+                    if (idx == 0x7fffffffu) idx = 0;
+                }
+                cur = (int)idx;
+                outv = lane == r ? cur : outv;
+            }
+            if (write && lane < rows) states[first + lane] = outv;
+            top = ntop;
+        }
+        return cur;
+    };
+
+    // Chunking, speculative warm-up and verification exactly as in lazy_backtrace_kernel.
+    const int Lf = Tb - 1;
+    if (MODE == 0) {
+        const int lo_c = (int)((long long)Lf * chunk / C), hi_c = (int)((long long)Lf * (chunk + 1) / C);
+        if (chunk == C - 1) {
+            for (int t = Tb + lane; t < T; t += 64) states[t] = -1;
+            if (lane == 0) states[Tb - 1] = a.last_state[song];
+        }
+        int top = hi_c - 1 + a.warm;
+        int cur;
+        if (chunk == C - 1 || top >= Lf - 1) {
+            top = Lf - 1;
+            cur = __builtin_amdgcn_readfirstlane(a.last_state[song]);
+        } else {
+            // guess: lowest-index argmax of delta row top+1
+            const float* g = hist + (size_t)(top + 1) * SD;
+            float d[EPL];
+            float m = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                d[e] = inS[e] ? g[e * 64 + lane] : -INFINITY;
+                m = fmaxf(m, d[e]);
+            }
+            m = wave_max_all(m);
+            unsigned idx = 0x7fffffffu;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const unsigned long long mk = __ballot(d[e] == m && inS[e]);
+                if (mk) { const unsigned c = e * 64 + __builtin_ctzll(mk); idx = c < idx ? c : idx; }
+            }
+            cur = idx == 0x7fffffffu ? 0 : (int)idx;
+        }
+        if (hi_c <= lo_c) {                       // empty chunk (very short song)
+            if (lane == 0) a.entry[(size_t)song * C + chunk] = cur;
+            return;
+        }
+        cur = chase(top, hi_c, cur, false);       // warm-up: frames top .. hi_c, nothing written
+        if (lane == 0) a.entry[(size_t)song * C + chunk] = cur;   // state this chunk assumed at frame hi_c
+        chase(hi_c - 1, lo_c, cur, true);
+    } else {
+        int truth = -1;                           // verified state at frame hi_c of the chunk being checked
+        for (int c = C - 2; c >= 0; --c) {
+            const int lo_c = (int)((long long)Lf * c / C), hi_c = (int)((long long)Lf * (c + 1) / C);
+            if (truth < 0) truth = __builtin_amdgcn_readfirstlane(states[hi_c]);
+            const int assumed = __builtin_amdgcn_readfirstlane(a.entry[(size_t)song * C + c]);
+            if (hi_c > lo_c && assumed != truth) {
+                truth = chase(hi_c - 1, lo_c, truth, true);   // re-chase from the true state; ends at frame lo_c
+            } else {
+                truth = -1;                       // chunk c stands: its frame lo_c is already in `states`
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Lazy back-trace: one wave per song (kBtWaves songs per workgroup share the LDS tables).
+// For frame t (descending) and the path state j at t+1 it rebuilds the candidates of target j
+//   fl(delta_t[i] + logA_T[j][i])   for every source i
+// from the stored delta row (window / c0 floor / extra columns / dense row, or the full matrix
+// row for unstructured matrices), takes the max over the wave and picks the LOWEST index
+// attaining it (v_cmp_eq lane masks + s_ff1).  Delta rows are staged through LDS in tiles of K
+// frames; the next tile is in flight in registers while the current one is chased.
+// ---------------------------------------------------------------------------------------
+constexpr int kBtWaves = 4;
 
 // MODE 0: speculative pass, one wave per (song, chunk).  MODE 1: verify pass, one wave per song.
 template <int NWT, int MODE>
@@ -884,13 +1102,14 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
     const int WX = W + nx;                  // window candidates + extra-column candidates, one per lane
     const bool fast_ok = banded && a.have_fmax && WX <= 64;
     // LDS: [tile per wave: kBtVec*64 float4][out per wave: 64 ints]
-    //      [tables: lo, kind, tabX = window rows then extra rows]
+    //      [tables: lo, kind, rowc, tabX[j][.] = the W window entries then the extra-column entries of target j]
     f32x4* tiles = reinterpret_cast<f32x4*>(smem);
     int32_t* outs = reinterpret_cast<int32_t*>(tiles + kBtWaves * kBtVec * 64);
     int32_t* loL = outs + kBtWaves * 64;
     int32_t* kindL = loL + SP;
     float* rowcL = reinterpret_cast<float*>(kindL + SP);  // [SP] row constants
-    float* tabX = rowcL + SP;                             // [(W + kMaxExtras)][SP]
+    float* tabX = rowcL + SP;                             // [SP][WXS]: one target's candidates are contiguous (lane l reads entry l: no bank conflicts)
+    const int WXS = W + kMaxExtras;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform for the compiler
@@ -901,8 +1120,8 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
         const float* gt = reinterpret_cast<const float*>(a.image + a.off_tabA);
         const float* gc = reinterpret_cast<const float*>(a.image + a.off_rowc);
         for (int k = tid; k < SP; k += kBtWaves * 64) { loL[k] = gl[k]; kindL[k] = gk[k]; rowcL[k] = gc[k]; }
-        for (int k = tid; k < W * SP; k += kBtWaves * 64) tabX[k] = gt[k];
-        for (int k = tid; k < kMaxExtras * SP; k += kBtWaves * 64) tabX[W * SP + k] = gx[k];
+        for (int k = tid; k < W * SP; k += kBtWaves * 64) tabX[(k % SP) * WXS + k / SP] = gt[k];
+        for (int k = tid; k < kMaxExtras * SP; k += kBtWaves * 64) tabX[(k % SP) * WXS + W + k / SP] = gx[k];
     }
     __syncthreads();
 
@@ -981,7 +1200,7 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
                 // ---- common case: only the window + extra-column candidates of target jj
                 const int src = lane < W ? lo + lane : xsrc;
                 float v = -INFINITY;
-                if (lane < WX) v = row[src] + tabX[lane * SP + jj];
+                if (lane < WX) v = row[src] + tabX[jj * WXS + lane];
                 const float m = wave_max_all(v);
                 const float mf = row[S] + rowcL[jj];  // pad column S = max_i delta_t[i] (non-extra): fl(. + c_jj) bounds every row-constant candidate
                 if (mf < m) {                    // no row-constant candidate can tie or win
@@ -1010,7 +1229,7 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
                 if (kd == -1) {
                     const float cjj = rowcL[jj];
                     const int src = lane < W ? lo + lane : xsrc;
-                    if (lane < WX) vw = row[src] + tabX[lane * SP + jj];
+                    if (lane < WX) vw = row[src] + tabX[jj * WXS + lane];
 #pragma unroll
                     for (int e = 0; e < EPL; ++e) {
                         const int i = e * 64 + lane;
@@ -1023,7 +1242,7 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
                             const int i = e * 64 + lane;
 #pragma unroll
                             for (int k = 0; k < kMaxExtras; ++k)
-                                if (k < nx && i == a.extras[k]) vf[e] = d[e] + tabX[(W + k) * SP + jj];
+                                if (k < nx && i == a.extras[k]) vf[e] = d[e] + tabX[jj * WXS + W + k];
                         }
                     }
                 } else if (kd >= 0) {
@@ -1190,26 +1409,14 @@ static hipError_t launch_banded_t(const FwdArgs& a, hipStream_t st) {
         hipLaunchKernelGGL((banded_pair_forward_kernel<W, NWT, ET>), dim3((int)a.B), dim3((NPW + 2) * 64), lds, st, a);
         return hipGetLastError();
     }
-    if (a.floor_ok && a.S < NP && !(a.debug & ~(48 | 16384 | 32768 | 0xf0000))) {   // one barrier, no scan waves (lane S stores the frame maximum: needs S < NP)
+    if (a.floor_ok && a.S < NP && !(a.debug & ~48)) {   // one barrier, no scan waves (lane S stores the frame maximum: needs S < NP)
         constexpr int NWM = (NWT + 3) / 4 * 4;
         const size_t ldsf = sizeof(float) * (8 * (NP + 16) + 2 * NWM + 64 + NWM) + sizeof(VI) * 16;
-        if (W == 32 && a.n_extras == 1) {
-            if (a.debug & 0x10000)
-                hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, (W == 32 ? 1 : -1), 4, ET, 1>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
-            else if (a.debug & 0x20000)
-                hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, (W == 32 ? 1 : -1), 4, ET, 2>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
-            else if (a.debug & 0x40000)
-                hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, (W == 32 ? 1 : -1), 4, ET, 3>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
-            else if (a.debug & 0x80000)
-                hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, (W == 32 ? 1 : -1), 4, ET, 4>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
-            else if (a.debug & 16384)
-                hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, (W == 32 ? 1 : -1), 2, ET>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
-            else if (a.debug & 32768)
-                hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, (W == 32 ? 1 : -1), 8, ET>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
-            else
-                hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, (W == 32 ? 1 : -1), 4, ET>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
-        } else
-            hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, -1, 4, ET>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
+        constexpr int PF = 4;   // emission rows in flight (2: 13.2 ms, 4: 11.2 ms, 8: 12.4 ms at B = 128)
+        if (W == 32 && a.n_extras == 1)   // the reference's matrices: band + unvoiced column
+            hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, (W == 32 ? 1 : -1), PF, ET>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
+        else
+            hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, -1, PF, ET>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
         return hipGetLastError();
     }
     const size_t lds = sizeof(float) * (4 * (NP + 16) + 2 * (NP + 1) + kMaxDenseRows) + sizeof(VI) * 16;
@@ -1270,10 +1477,39 @@ int backtrace_tile_rows(int SD) {
     return k > 64 ? 64 : (k < 1 ? 1 : k);
 }
 
+constexpr size_t kLdsBytes = 160 * 1024;
+
+template <int NWT, bool AFF>
+static hipError_t launch_bt_lean(const BtArgs& a, int nwaves, size_t lds, hipStream_t st) {
+    const long long waves0 = (long long)a.B * a.chunks;
+    hipLaunchKernelGGL((banded_backtrace_kernel<NWT, AFF, 0>), dim3((int)((waves0 + nwaves - 1) / nwaves)), dim3(nwaves * 64), lds, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || a.chunks <= 1) return e;
+    hipLaunchKernelGGL((banded_backtrace_kernel<NWT, AFF, 1>), dim3((int)((a.B + nwaves - 1) / nwaves)), dim3(nwaves * 64), lds, st, a);
+    return hipGetLastError();
+}
+
 template <int NWT>
-static hipError_t launch_bt_t(const BtArgs& a, hipStream_t st) {
+static hipError_t launch_bt_t(BtArgs a, hipStream_t st) {
+    // lean kernel: banded plan, no dense rows, frame maxima stored by the forward pass, candidates fit lanes 0..61
+    if (a.banded && a.have_fmax && a.n_dense == 0 && a.W <= 32 && a.W + a.n_extras <= 62 && !(a.debug & 2048)) {
+        const size_t tables = sizeof(float) * a.SP * (2 + a.W + kMaxExtras);
+        for (int nw = 8; nw >= 1; nw >>= 1) {
+            const size_t lds = sizeof(f32x4) * kBtVec * 64 * nw + tables;
+            if (lds + 1024 > kLdsBytes) continue;
+            return a.lo_affine ? launch_bt_lean<NWT, true>(a, nw, lds, st) : launch_bt_lean<NWT, false>(a, nw, lds, st);
+        }
+    }
     size_t lds = sizeof(f32x4) * kBtWaves * kBtVec * 64 + sizeof(int32_t) * kBtWaves * 64;
-    if (a.banded) lds += sizeof(int32_t) * 2 * a.SP + sizeof(float) * (1 + kMaxExtras + a.W) * a.SP;
+    if (a.banded) {
+        const size_t tables = sizeof(int32_t) * 2 * a.SP + sizeof(float) * (1 + kMaxExtras + a.W) * a.SP;
+        if (lds + tables + 1024 > kLdsBytes) {   // tables do not fit: evaluate full matrix rows instead (exact, slower)
+            a.banded = 0;
+            a.have_fmax = 0;
+        } else {
+            lds += tables;
+        }
+    }
     const long long waves0 = (long long)a.B * a.chunks;
     hipLaunchKernelGGL((lazy_backtrace_kernel<NWT, 0>), dim3((int)((waves0 + kBtWaves - 1) / kBtWaves)), dim3(kBtWaves * 64),
                        lds, st, a);
