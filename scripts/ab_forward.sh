@@ -1,8 +1,8 @@
 #!/bin/bash
-# interleaved A/B of forward-kernel variants (VIT_DEBUG_FLAGS = 4096 * OPT) on the same box
+# A/B of forward-kernel variants selected by VIT_DEBUG_FLAGS (timing experiments)
 cd "$(dirname "$0")/.."
-for r in 1 2; do
- for o in 0 1 2 4; do
-  VIT_DEBUG_FLAGS=$((4096*o)) python bench.py --steps 4 --warmup 1 --no-cpu-baseline --batch ${PB:-128} 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('round', $r, 'OPT', $o, 'fwd_ms', round(d['kernels_ms']['forward'],3))"
- done
+for f in ${FLAGS:-0 4096}; do
+  for b in ${BATCHES:-1 128 512}; do
+    VIT_DEBUG_FLAGS=$f python bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch $b 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('flags', $f, 'B', $b, 'Mframes/s', round(d['value'],1), 'fwd_ms', round(d['kernels_ms']['forward'],2), 'bt_ms', round(d['kernels_ms']['backtrace'],2), 'exact', d.get('cpu_baseline'))"
+  done
 done

@@ -610,10 +610,13 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
         for (int q = 0; q < NWT / 4; ++q) wq[q] = reinterpret_cast<const f32x4*>(wm + RB * NWM)[q];
         if (NWT % 4 >= 2) wr = *reinterpret_cast<const f32x2*>(wm + RB * NWM + (NWT / 4) * 4);
         if (NWT % 4 == 1 || NWT % 4 == 3) wl = wm[RB * NWM + NWT - 1];
+        f32x4 dw[W / 4];
+#pragma unroll
+        for (int q = 0; q < W / 4; ++q) dw[q] = win[q];
         float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
 #pragma unroll
         for (int w = 0; w + 7 < W; w += 8) {
-            const f32x4 da = win[w / 4], db = win[w / 4 + 1];
+            const f32x4 da = dw[w / 4], db = dw[w / 4 + 1];
             const f32x2 c0_ = f32x2{da.x, da.y} + f32x2{aw[w + 0], aw[w + 1]};
             const f32x2 c1_ = f32x2{da.z, da.w} + f32x2{aw[w + 2], aw[w + 3]};
             const f32x2 c2_ = f32x2{db.x, db.y} + f32x2{aw[w + 4], aw[w + 5]};
@@ -633,12 +636,12 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
         for (int k = 0; k < NXL; ++k) m1 = fmaxf(m1, xd[k] + xa[k]);
         const float dn = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)) + e_slot;
         produce(dn, WB);
-        // unconditional store + prefetch: exact in-order vmcnt accounting (see banded_forward_kernel)
-        float* __restrict__ hb = hist + (size_t)(t - 1) * SD;
+        // Unconditional store + prefetch: exact in-order vmcnt accounting (see banded_forward_kernel).  Row bases are
+        // scalar index arithmetic on purpose: the SALU is idle, the VALU is not (running 64-bit per-lane pointers
+        // measured 3.5% slower).
         const int tn = t + PF < Tb ? t + PF : Tb - 1;
-        const ET* __restrict__ erow = E + (size_t)tn * S;
-        hb[hoff] = is_fm ? M : dn;
-        e_slot = load_e<ET>(erow + jld);
+        hist[(size_t)(t - 1) * SD + hoff] = is_fm ? M : dn;
+        e_slot = load_e<ET>(E + (size_t)tn * S + jld);
         __syncthreads();
     };
     const bool probe = (a.debug & 48) != 0;
