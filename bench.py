@@ -171,6 +171,11 @@ def main():
             except Exception:
                 bt_traffic = None
         SD = (S + 5) // 4 * 4
+        fwd_kernel = "dense_forward_kernel"
+        if algo == "banded":   # same rule as launch_banded_t (kernels.hip)
+            nwt = next((w for w in (2, 4, 6, 8, 12) if w * 64 >= S), 0)
+            floor_form = dec.info["floor_ok"] and dec.info["n_dense_rows"] == 0 and S < nwt * 64
+            fwd_kernel = "banded_floor_forward_kernel" if floor_form else "banded_forward_kernel"
         out = {
             "metric": "Viterbi Mframes/s at S=361 T=30k; achieved HBM GB/s vs peak",
             "value": value, "unit": "Mframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -181,7 +186,7 @@ def main():
                                    + (" + RCCL gather of paths" if world > 1 else ""),
                        "songs_per_gpu": B, "frames": T, "states": S, "emissions": args.emissions,
                        "transition": args.transition, "forward_kernel": algo, "plan": dec.info},
-            "roofline": {"bound": "hbm", "kernel": f"{algo}_forward_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": fwd_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": fwd_bytes, "avg_launch_ms": fwd_ms,
                          "bytes_per_frame": S * esize + S * 2,
@@ -190,7 +195,8 @@ def main():
                                  "and the recursion is fp32-VALU / latency bound, not HBM bound"},
             "kernels_ms": {"forward": fwd_ms, "backtrace": bt_ms},
             "backtrace": {"algorithmic_bytes_per_launch": bt_bytes, "traffic": bt_traffic,
-                          "implementation_bytes_per_frame": SD * 4},
+                          "implementation_bytes_per_frame": SD * 4,
+                          "hbm_gbs_from_traffic": (bt_traffic / (bt_ms * 1e-3) / 1e9) if bt_traffic else None},
             "whole_path_bytes_per_frame": S * esize + S * 2 + 6,
             "whole_path_hbm_frac": value * 1e6 * (S * esize + S * 2 + 6) / 1e9 / (HBM_PEAK_GBS * world),
         }
