@@ -106,6 +106,7 @@ int vit_plan_query(const vit_plan* plan, vit_plan_info* info) {
     info->group_window = plan->bp.W;
     info->reserved[0] = plan->bp.n_dense;
     info->reserved[1] = plan->bp.ok && plan->bp.floor_ok ? 1 : 0;
+    info->reserved[2] = plan->bp.ok && plan->bp.lo_affine ? 1 : 0;
     info->consts[0] = plan->bp.c0;
     for (int k = 0; k < vit::kMaxExtras; ++k) info->extras[k] = k < plan->bp.n_extras ? plan->bp.extras[k] : -1;
     return VIT_OK;

@@ -1412,7 +1412,7 @@ static hipError_t launch_banded_t(const FwdArgs& a, hipStream_t st) {
         hipLaunchKernelGGL((banded_pair_forward_kernel<W, NWT, ET>), dim3((int)a.B), dim3((NPW + 2) * 64), lds, st, a);
         return hipGetLastError();
     }
-    if (a.floor_ok && a.S < NP && !(a.debug & ~48)) {   // one barrier, no scan waves (lane S stores the frame maximum: needs S < NP)
+    if (a.floor_ok && a.S < NP && !(a.debug & ~(48 | 2048))) {   // 2048 only selects the generic back-trace   // one barrier, no scan waves (lane S stores the frame maximum: needs S < NP)
         constexpr int NWM = (NWT + 3) / 4 * 4;
         const size_t ldsf = sizeof(float) * (8 * (NP + 16) + 2 * NWM + 64 + NWM) + sizeof(VI) * 16;
         constexpr int PF = 4;   // emission rows in flight (2: 13.2 ms, 4: 11.2 ms, 8: 12.4 ms at B = 128)
@@ -1428,7 +1428,7 @@ static hipError_t launch_banded_t(const FwdArgs& a, hipStream_t st) {
     // otherwise lengthen the suffix wave, the critical one).
     if (a.n_dense > 0 && a.B <= 256)
         hipLaunchKernelGGL((banded_forward_kernel<W, NWT, true, false, -1, ET>), dim3((int)a.B), dim3((NWT + 3) * 64), lds, st, a);
-    else if (a.debug)
+    else if (a.debug & ~2048)
         hipLaunchKernelGGL((banded_forward_kernel<W, NWT, false, true, -1, ET>), dim3((int)a.B), dim3((NWT + 2) * 64), lds, st, a);
     else if (W == 32 && a.n_dense == 0 && a.n_extras == 1)   // the reference's matrices: band + unvoiced column
         hipLaunchKernelGGL((banded_forward_kernel<W, NWT, false, false, (W == 32 ? 1 : -1), ET>), dim3((int)a.B), dim3((NWT + 2) * 64), lds, st, a);
