@@ -636,6 +636,8 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
         for (int k = 0; k < NXL; ++k) m1 = fmaxf(m1, xd[k] + xa[k]);
         const float dn = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)) + e_slot;
         produce(dn, WB);
+        asm volatile("" ::: "memory");   // keep the global store / prefetch behind the wave-max publication: they fill the
+                                         // wait for the LDS write acknowledgement before the barrier (-2 %)
         // Unconditional store + prefetch: exact in-order vmcnt accounting (see banded_forward_kernel).  Row bases are
         // scalar index arithmetic on purpose: the SALU is idle, the VALU is not (running 64-bit per-lane pointers
         // measured 3.5% slower).
