@@ -175,7 +175,9 @@ def main():
         if algo == "banded":   # same rule as launch_banded_t (kernels.hip)
             nwt = next((w for w in (2, 4, 6, 8, 12) if w * 64 >= S), 0)
             floor_form = dec.info["floor_ok"] and dec.info["n_dense_rows"] == 0 and S < nwt * 64
-            fwd_kernel = "banded_floor_forward_kernel" if floor_form else "banded_forward_kernel"
+            fwd_kernel = "banded_forward_kernel"
+            if floor_form:
+                fwd_kernel = "banded_floor_pair_forward_kernel" if (dec.info["pair_ok"] and B > 256 and nwt <= 8 and dec.info["group_window"] <= 32) else "banded_floor_forward_kernel"
         out = {
             "metric": "Viterbi Mframes/s at S=361 T=30k; achieved HBM GB/s vs peak",
             "value": value, "unit": "Mframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

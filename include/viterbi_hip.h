@@ -73,7 +73,7 @@ typedef struct vit_plan_info {
     int32_t n_extras;       /* extra exception columns shared by most rows */
     int32_t max_window;     /* widest per-row exception window */
     int32_t group_window;   /* window width the banded kernel evaluates per target */
-    int32_t reserved[3];    /* [0] dense rows, [1] one-maximum ("floor") form proven, [2] window start affine in the target */
+    int32_t reserved[3];    /* [0] dense rows, [1] one-maximum ("floor") form proven, [2] bit 0: window start affine in the target, bit 1: pair windows proven */
     float consts[4];
     int32_t extras[4];
 } vit_plan_info;

@@ -34,7 +34,7 @@ class HostPlan:
         h = lib.vph_create(A.ctypes.data, pi.ctypes.data, S)
         info = np.zeros(16, np.int32)
         c0 = np.zeros(1, np.float32)
-        off = np.zeros(10, np.int64)
+        off = np.zeros(12, np.int64)
         lib.vph_info(h, info.ctypes.data, c0.ctypes.data)
         lib.vph_offsets(h, off.ctypes.data)
         img = np.zeros(int(off[7]), np.uint8)
@@ -61,9 +61,11 @@ class HostPlan:
         self.denseA = sec(6, np.float32, 4 * SP).reshape(4, SP)
         self.Arow = sec(8, np.float32, self.S * SP).reshape(self.S, SP)
         self.rowc = sec(9, np.float32, SP)
+        self.lo2 = sec(10, np.int32, SP // 2)
+        self.tabP = sec(11, np.float32, max(self.W, 1) * SP).reshape(max(self.W, 1), SP)
 
 
-def replay_banded(plan: HostPlan, logE, floor=False):
+def replay_banded(plan: HostPlan, logE, floor=False, pair=False):
     """Follows the GPU kernels step by step on the host.
 
     Forward (banded_forward_kernel): value-only; per target the max of the W window sums, of
@@ -77,6 +79,7 @@ def replay_banded(plan: HostPlan, logE, floor=False):
     Returns (states int64[T], loglik, final delta[S])."""
     assert plan.ok
     assert plan.floor_ok or not floor
+    assert (plan.pair_ok and floor) or not pair
     S, W = plan.S, plan.W
     logE = np.ascontiguousarray(logE, np.float32)
     T = logE.shape[0]
@@ -85,6 +88,10 @@ def replay_banded(plan: HostPlan, logE, floor=False):
     rowc = plan.rowc[:S]
     win_idx = lo[:, None] + np.arange(W)[None, :]            # [S,W]
     tab = plan.tabA[:, :S].T                                  # [S,W]
+    if pair:   # banded_floor_pair_forward_kernel: targets 2p, 2p+1 evaluate the common window lo2[p] .. lo2[p]+W
+        lo2 = plan.lo2[np.arange(S) // 2].astype(np.int64)
+        win_idx = lo2[:, None] + np.arange(W)[None, :]
+        tab = plan.tabP[:, :S].T
     masked = np.zeros(S, bool)
     masked[plan.extras] = True
     ninf = np.float32(-np.inf)

@@ -61,6 +61,10 @@ def test_banded_replay_is_bit_exact(golden, pname, kind, T, seed):
     assert plan.floor_ok
     st2, ll2, delta2 = replay_banded(plan, E, floor=True)
     assert np.array_equal(st2, ref) and delta2.tobytes() == rdelta.tobytes()
+    # ... and for the two-targets-per-lane form (one W-wide window per pair of adjacent targets)
+    assert plan.pair_ok
+    st3, ll3, delta3 = replay_banded(plan, E, floor=True, pair=True)
+    assert np.array_equal(st3, ref) and delta3.tobytes() == rdelta.tobytes()
 
 
 def _banded_matrix(S, half, rng, extras=(), dense_rows=(), floor=-50.0, quant=4):
@@ -98,6 +102,9 @@ def test_random_banded_structures_with_ties(seed):
     if plan.floor_ok:
         st2, _, delta2 = replay_banded(plan, E, floor=True)
         assert np.array_equal(st2, ref) and delta2.tobytes() == rdelta.tobytes()
+        if plan.pair_ok:
+            st3, _, delta3 = replay_banded(plan, E, floor=True, pair=True)
+            assert np.array_equal(st3, ref) and delta3.tobytes() == rdelta.tobytes()
 
 
 def _window_ge_floor(A, plan):

@@ -106,7 +106,7 @@ int vit_plan_query(const vit_plan* plan, vit_plan_info* info) {
     info->group_window = plan->bp.W;
     info->reserved[0] = plan->bp.n_dense;
     info->reserved[1] = plan->bp.ok && plan->bp.floor_ok ? 1 : 0;
-    info->reserved[2] = plan->bp.ok && plan->bp.lo_affine ? 1 : 0;
+    info->reserved[2] = (plan->bp.ok && plan->bp.lo_affine ? 1 : 0) | (plan->bp.ok && plan->bp.pair_ok ? 2 : 0);
     info->consts[0] = plan->bp.c0;
     for (int k = 0; k < vit::kMaxExtras; ++k) info->extras[k] = k < plan->bp.n_extras ? plan->bp.extras[k] : -1;
     return VIT_OK;
@@ -182,6 +182,9 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
     a.off_tabP = plan->L.off_tabP;
     a.pair_ok = plan->bp.ok && plan->bp.pair_ok ? 1 : 0;
     a.floor_ok = plan->bp.ok && plan->bp.floor_ok ? 1 : 0;
+    a.win_shift = (plan->bp.ok && plan->bp.lo_affine) ? (plan->bp.lo_off & 3) : 0;
+    a.win_shift2 = (plan->bp.ok && plan->bp.pair_ok && plan->bp.lo2_affine) ? (plan->bp.lo2_off & 3) : 0;
+    if (const char* e = std::getenv("VIT_WIN_SHIFT")) a.win_shift = a.win_shift2 = std::atoi(e) & 3;   // timing experiments only
 
     hipError_t e;
     if (algo == VIT_ALGO_BANDED) {

@@ -561,9 +561,14 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
             is_x |= (k < nx && j == xcol[k]);
         }
     }
-    const int lov = tvalid ? lo : 0;
+    // delta[i] lives at float position 4 + sh + i - c of copy c (sh = a.win_shift): lane j reads its window from the copy
+    // that makes delta[lo_j] 16-byte aligned.  With sh = lo_off mod 4 the sixteen lanes of one LDS read group start on
+    // sixteen different 4-bank groups; without it the first and the last lane of a group collide (2-way conflict on
+    // every ds_read_b128: 128 instead of 256 B/clk).
+    const int sh = a.win_shift;
+    const int lov = (tvalid ? lo : 0) + sh;
     const float* rp = dls + 4 + (lov & 3) * DC + (lov & ~3);              // window start in the copy that aligns it
-    float* wp = dls + 4 + j;                                              // own entry of copy 0 (copy c: + c*DC - c)
+    float* wp = dls + 4 + sh + j;                                         // own entry of copy 0 (copy c: + c*DC - c)
     float* wmp = lane == 63 ? wm + wv : dump + lane;                      // lane 63 ends up with the wave maximum
 
     for (int k = tid; k < 2 * BUF + 2 * NWM; k += NWT * 64) dls[k] = -INFINITY;
@@ -601,7 +606,7 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
         const f32x4* __restrict__ win = reinterpret_cast<const f32x4*>(rp + RB * BUF);
         float xd[NXL > 0 ? NXL : 1];
 #pragma unroll
-        for (int k = 0; k < NXL; ++k) xd[k] = dls[4 + RB * BUF + xcol[k]];
+        for (int k = 0; k < NXL; ++k) xd[k] = dls[4 + sh + RB * BUF + xcol[k]];
         // the NWT wave maxima: whole float4s, plus one float2 when NWT % 4 is 2 or 3 (slots >= NWT hold -inf)
         f32x4 wq[NWT / 4 > 0 ? NWT / 4 : 1];
         f32x2 wr = f32x2{-INFINITY, -INFINITY};
@@ -659,7 +664,7 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
         if (t + k < Tb) frame(t + k, er[k], k & 1);
 
     const int fb = (Tb - 1) & 1;                                          // buffer holding delta_{Tb-1}
-    terminal_argmax(tvalid ? dls[4 + fb * BUF + j] : -INFINITY, j, tvalid, tot, NWT, a.last_state, a.loglik, song);
+    terminal_argmax(tvalid ? dls[4 + sh + fb * BUF + j] : -INFINITY, j, tvalid, tot, NWT, a.last_state, a.loglik, song);
     if (probe && tid == 0 && a.loglik) {  // timing experiments only: cycles (16) or 100 MHz ticks (32) per frame
         const unsigned long long d = (a.debug & 16) ? __builtin_amdgcn_s_memtime() - clk0 : __builtin_amdgcn_s_memrealtime() - rt0;
         a.loglik[song] = (float)d / (float)(Tb > 1 ? Tb - 1 : 1);
@@ -667,24 +672,32 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
 }
 
 // ---------------------------------------------------------------------------------------
-// Banded forward kernel, two targets per lane (the plan proved "pair windows": targets 2p and
-// 2p+1 both fit one window [lo2_p, lo2_p + W + 2)).  Same arithmetic as banded_forward_kernel;
-// the point is issue slots: a wave issues at most one instruction (of any kind) per 4-cycle SIMD
-// turn, and sharing the window reads between two targets needs 17 LDS reads + waits per pair
-// instead of 32, and only ceil(S/128) target waves (one per SIMD at S = 361) plus two scan waves.
+// Floor-max banded forward kernel, two targets per lane (plan.pair_ok && plan.floor_ok; what the bench runs).
+//
+// What bounds a frame of banded_floor_forward_kernel is the LDS return path: every target pulls its own W floats
+// into registers (46 KB per frame at S = 361) and ds_read_b128 delivers ~128 B/clk per CU, ~380 of the ~870 cycles.
+// The plan proves that the exception spans of targets 2p and 2p+1 together fit one window [lo2_p, lo2_p + W); entries
+// of that window outside a row's own span are that row's constant (or an extra column), i.e. still >= c_j, so the
+// floor-max identity holds for the common window.  One lane therefore evaluates BOTH targets from one set of W/4
+// window reads: half the LDS traffic and half the waves (three at S = 361, one per SIMD), the same packed adds and
+// max3 per target.  Everything else is as in banded_floor_forward_kernel.
 // ---------------------------------------------------------------------------------------
-template <int W, int NWT, typename ET>
-__global__ void __launch_bounds__(((NWT + 1) / 2 + 2) * 64) banded_pair_forward_kernel(FwdArgs a) {
+template <int W, int NPW, int NXT, int PF, typename ET>
+__global__ void __launch_bounds__(NPW * 64) banded_floor_pair_forward_kernel(FwdArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int NP = NWT * 64;           // padded state count (scan waves: NWT sources per lane)
-    constexpr int EPL = NWT;
-    constexpr int NPW = (NWT + 1) / 2;     // target waves: one lane per pair of targets
-    constexpr int WP = W + 2;              // common window of a pair
+    constexpr int NP = NPW * 128;                 // padded state count
+    constexpr int DC = NP + 16;                   // copy stride (see banded_forward_kernel)
+    constexpr int BUF = 4 * DC;                   // floats per delta buffer
+    constexpr int NWM = 4;                        // wave maxima per buffer (NPW <= 4), one float4
+    static_assert(NPW <= 4, "one float4 of wave maxima");
+    float* dls = reinterpret_cast<float*>(smem);  // [2][4][DC]
+    float* wm = dls + 2 * BUF;                    // [2][NWM]
+    float* dump = wm + 2 * NWM;                   // [64 + NWM]
+    VI* tot = reinterpret_cast<VI*>(dump + 64 + NWM);
     const int S = a.S, SP = a.SP, T = a.T, SD = a.SD;
-    float* dl = reinterpret_cast<float*>(smem);   // [NP]    delta_{t-1}; entries >= S stay -inf
-    float* Pv = dl + NP;                          // [NP+1]  Pv[q] = max_{i<q}  raw delta (extras excluded)
-    float* Sv = Pv + NP + 1;                      // [NP+1]  Sv[q] = max_{i>=q} raw delta
-    VI* tot = reinterpret_cast<VI*>(Sv + NP + 1);  // [16]; 3*NP + 2 floats precede it: 8-byte aligned
+    constexpr bool GEN = NXT < 0;
+    constexpr int NXL = GEN ? kMaxExtras : NXT;
+    const int nx = GEN ? a.n_extras : NXT;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -693,156 +706,146 @@ __global__ void __launch_bounds__(((NWT + 1) / 2 + 2) * 64) banded_pair_forward_
     const int Tb = song_length(a.lengths, song, T);
     const ET* __restrict__ E = reinterpret_cast<const ET*>(a.logE) + (size_t)song * T * S;
     float* __restrict__ hist = a.hist + (size_t)song * T * SD;
-    const int nx = a.n_extras;
-    const int dbg = a.debug;
 
-    // ---------------- per-role setup
-    const bool is_target = wv < NPW;
-    const int j0 = 2 * tid, j1 = 2 * tid + 1;          // this lane's two targets
-    const bool v0 = is_target && j0 < S, v1 = is_target && j1 < S;
+    // ---------------- per-lane constants.  Slots past S carry -inf tables: their delta stays -inf.
+    const int j0 = 2 * tid, j1 = 2 * tid + 1;
+    const bool v0 = j0 < S, v1 = j1 < S;
     const int jc0 = v0 ? j0 : 0, jc1 = v1 ? j1 : jc0;
-    int lo = 0;
-    float cj0 = 0.f, cj1 = 0.f;
-    float aw0[WP], aw1[WP];
-    float xa0[kMaxExtras], xa1[kMaxExtras];
-    int xcol[kMaxExtras];
-#pragma unroll
-    for (int k = 0; k < kMaxExtras; ++k) { xa0[k] = xa1[k] = -INFINITY; xcol[k] = a.extras[k]; }
-#pragma unroll
-    for (int w = 0; w < WP; ++w) aw0[w] = aw1[w] = 0.f;
-    if (is_target) {
-        lo = reinterpret_cast<const int32_t*>(a.image + a.off_lo2)[jc0 >> 1];
-        const float* __restrict__ rc = reinterpret_cast<const float*>(a.image + a.off_rowc);
+    const int jl0 = v0 ? j0 : S - 1, jl1 = v1 ? j1 : S - 1;               // emission columns (idle slots load a valid one)
+    // history stores of frame t, relative to row t-1: own column of row t | slot S: M into pad column S of row t-1
+    // | other idle slots: pad column S+1 of row t (never read)
+    const unsigned hoff0 = v0 ? (unsigned)(SD + j0) : (j0 == S ? (unsigned)S : (unsigned)(SD + S + 1));
+    const unsigned hoff1 = v1 ? (unsigned)(SD + j1) : (j1 == S ? (unsigned)S : (unsigned)(SD + S + 1));
+    const bool fm0 = j0 == S, fm1 = j1 == S;
+    const int lo2 = v0 ? reinterpret_cast<const int32_t*>(a.image + a.off_lo2)[jc0 >> 1] : 0;
+    const float* __restrict__ rc = reinterpret_cast<const float*>(a.image + a.off_rowc);
+    f32x2 cj = f32x2{v0 ? rc[jc0] : -INFINITY, v1 ? rc[jc1] : -INFINITY};
+    float aw0[W], aw1[W];
+    f32x2 xa[NXL > 0 ? NXL : 1];
+    int xcol[NXL > 0 ? NXL : 1];
+    bool x0 = false, x1 = false;                                          // slot is an extra column: not part of M
+    {
         const float* __restrict__ tab = reinterpret_cast<const float*>(a.image + a.off_tabP);
         const float* __restrict__ xaT = reinterpret_cast<const float*>(a.image + a.off_extraA);
-        cj0 = rc[jc0];
-        cj1 = rc[jc1];
 #pragma unroll
-        for (int w = 0; w < WP; ++w) { aw0[w] = tab[(size_t)w * SP + jc0]; aw1[w] = tab[(size_t)w * SP + jc1]; }
+        for (int w = 0; w < W; ++w) {
+            aw0[w] = v0 ? tab[(size_t)w * SP + jc0] : -INFINITY;
+            aw1[w] = v1 ? tab[(size_t)w * SP + jc1] : -INFINITY;
+        }
 #pragma unroll
-        for (int k = 0; k < kMaxExtras; ++k) { xa0[k] = xaT[(size_t)k * SP + jc0]; xa1[k] = xaT[(size_t)k * SP + jc1]; }
+        for (int k = 0; k < NXL; ++k) {
+            xcol[k] = k < nx ? a.extras[k] : 0;
+            xa[k] = f32x2{(v0 && k < nx) ? xaT[(size_t)k * SP + jc0] : -INFINITY, (v1 && k < nx) ? xaT[(size_t)k * SP + jc1] : -INFINITY};
+            x0 |= (k < nx && j0 == xcol[k]);
+            x1 |= (k < nx && j1 == xcol[k]);
+        }
     }
-    const int role = wv - NPW;                 // 0 prefix scan, 1 suffix scan
-    const int blk = role == 1 ? 63 - lane : lane;
-    const int i0 = blk * EPL;
-    bool smask[EPL];
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-        const int i = i0 + e;
-        bool m = i >= S;
-#pragma unroll
-        for (int k = 0; k < kMaxExtras; ++k) m |= (k < nx && i == xcol[k]);
-        smask[e] = m;
-    }
+    // delta[i] lives at float position 4 + sh + i - c of copy c; the lane reads the common window from the copy that
+    // makes delta[lo2] 16-byte aligned (sh: see banded_floor_forward_kernel)
+    const int sh = a.win_shift2;
+    const int lov = lo2 + sh;
+    const float* rp = dls + 4 + (lov & 3) * DC + (lov & ~3);
+    float* wp = dls + 4 + sh + j0;                                        // slot 0 of copy 0 (copy c: + c*DC - c), slot 1 follows
+    float* wmp = lane == 63 ? wm + wv : dump + lane;
 
-    // ---------------- frame 0
-    const float* __restrict__ lpi = reinterpret_cast<const float*>(a.image + a.off_logpi);
-    if (is_target) {
-        float d0 = -INFINITY, d1 = -INFINITY;
-        if (v0) { d0 = lpi[j0] + load_e<ET>(E + j0); hist[j0] = d0; }
-        if (v1) { d1 = lpi[j1] + load_e<ET>(E + j1); hist[j1] = d1; }
-        if (j1 < NP) { dl[j0] = d0; dl[j1] = d1; }
-    } else if (lane == 0) {
-        if (role == 0) Pv[0] = -INFINITY;
-        if (role == 1) Sv[NP] = -INFINITY;
-    }
-    // emission rows are fetched two frames ahead and consumed at the end of a frame (in-order vmcnt)
-    float ea0 = (v0 && Tb > 1) ? load_e<ET>(E + S + j0) : 0.f, ea1 = (v1 && Tb > 1) ? load_e<ET>(E + S + j1) : 0.f;
-    float eb0 = (v0 && Tb > 2) ? load_e<ET>(E + 2 * (size_t)S + j0) : 0.f, eb1 = (v1 && Tb > 2) ? load_e<ET>(E + 2 * (size_t)S + j1) : 0.f;
-#pragma unroll
-    for (int w = 0; w < WP; ++w) asm volatile("" ::"v"(aw0[w]), "v"(aw1[w]));
-#pragma unroll
-    for (int k = 0; k < kMaxExtras; ++k) asm volatile("" ::"v"(xa0[k]), "v"(xa1[k]));
-    asm volatile("" ::"v"(lo), "v"(cj0), "v"(cj1), "v"(ea0), "v"(ea1), "v"(eb0), "v"(eb1));
+    for (int k = tid; k < 2 * BUF + 2 * NWM; k += NPW * 64) dls[k] = -INFINITY;
     __syncthreads();
 
-    auto frame = [&](const int t, float& es0, float& es1) {
-        float m0 = -INFINITY, m1 = -INFINITY;
-        if (is_target) {
-            // ---- the two window maxima (read delta_{t-1}); two max3 chains per target
-            float n0 = -INFINITY, n1 = -INFINITY;
+    auto produce = [&](const f32x2 dn, const int WB) {
 #pragma unroll
-            for (int k = 0; k < kMaxExtras; ++k)
-                if (k < nx) { const float dx = dl[xcol[k]]; m0 = fmaxf(m0, dx + xa0[k]); m1 = fmaxf(m1, dx + xa1[k]); }
-            if (!(dbg & 1)) {
-                float dw[WP];
-#pragma unroll
-                for (int w = 0; w < WP; ++w) dw[w] = dl[lo + w];
-#pragma unroll
-                for (int w = 0; w + 3 < WP; w += 4) {
-                    const f32x2 a0 = f32x2{dw[w], dw[w + 1]} + f32x2{aw0[w], aw0[w + 1]};
-                    const f32x2 a1 = f32x2{dw[w + 2], dw[w + 3]} + f32x2{aw0[w + 2], aw0[w + 3]};
-                    const f32x2 b0 = f32x2{dw[w], dw[w + 1]} + f32x2{aw1[w], aw1[w + 1]};
-                    const f32x2 b1 = f32x2{dw[w + 2], dw[w + 3]} + f32x2{aw1[w + 2], aw1[w + 3]};
-                    m0 = fmaxf(fmaxf(m0, a0.x), a0.y);
-                    n0 = fmaxf(fmaxf(n0, a1.x), a1.y);
-                    m1 = fmaxf(fmaxf(m1, b0.x), b0.y);
-                    n1 = fmaxf(fmaxf(n1, b1.x), b1.y);
-                }
-                if (WP % 4 == 2) {
-                    const f32x2 a0 = f32x2{dw[WP - 2], dw[WP - 1]} + f32x2{aw0[WP - 2], aw0[WP - 1]};
-                    const f32x2 b0 = f32x2{dw[WP - 2], dw[WP - 1]} + f32x2{aw1[WP - 2], aw1[WP - 1]};
-                    m0 = fmaxf(fmaxf(m0, a0.x), a0.y);
-                    m1 = fmaxf(fmaxf(m1, b0.x), b0.y);
-                }
-            }
-            m0 = fmaxf(m0, n0);
-            m1 = fmaxf(m1, n1);
-        } else if (!(dbg & 2)) {
-            float d[EPL], p[EPL];
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) d[e] = dl[i0 + e];
-            float run = -INFINITY;
-            if (role == 0) {
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) { run = fmaxf(run, smask[e] ? -INFINITY : d[e]); p[e] = run; }
-                const float inc = wave_scan_max(run);
-                const float ex = wave_shift_up(inc, -INFINITY);                 // sources of all lower lanes
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) Pv[i0 + e + 1] = fmaxf(ex, p[e]);
-                // max of delta_{t-1} over the non-extra sources: bounds every row-constant candidate in the back-trace
-                if (lane == 63 && !(dbg & 8)) hist[(size_t)(t - 1) * SD + S] = inc;   // pad column S of row t-1
-            } else {
-#pragma unroll
-                for (int e = EPL - 1; e >= 0; --e) { run = fmaxf(run, smask[e] ? -INFINITY : d[e]); p[e] = run; }
-                const float ex = wave_shift_up(wave_scan_max(run), -INFINITY);  // sources of all higher blocks
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) Sv[i0 + e] = fmaxf(ex, p[e]);
-            }
+        for (int c = 0; c < 4; ++c) {
+            wp[WB * BUF + c * DC - c] = dn.x;
+            wp[WB * BUF + c * DC - c + 1] = dn.y;
         }
-        __syncthreads();
+        const float inc = wave_scan_max(fmaxf((NXL > 0 && x0) ? -INFINITY : dn.x, (NXL > 0 && x1) ? -INFINITY : dn.y));
+        wmp[WB * NWM] = inc;
+    };
 
-        if (is_target && !(dbg & 4)) {
-            const float outside = fmaxf(Pv[lo], Sv[lo + WP]);
-            m0 = fmaxf(m0, outside + cj0);
-            m1 = fmaxf(m1, outside + cj1);
-            const float dn0 = m0 + es0, dn1 = m1 + es1;
-            if (j1 < NP) { dl[j0] = v0 ? dn0 : -INFINITY; dl[j1] = v1 ? dn1 : -INFINITY; }
-            if (!(dbg & 8)) {
-                float* __restrict__ hrow = hist + (size_t)t * SD;          // wave-uniform row bases
-                const ET* __restrict__ erow = E + (size_t)(t + 2) * S;
-                if (v0) hrow[j0] = dn0;
-                if (v1) hrow[j1] = dn1;
-                if (t + 2 < Tb) {
-                    if (v0) es0 = load_e<ET>(erow + j0);
-                    if (v1) es1 = load_e<ET>(erow + j1);
-                }
-            }
+    // ---------------- frame 0
+    {
+        const float* __restrict__ lpi = reinterpret_cast<const float*>(a.image + a.off_logpi);
+        f32x2 d0 = f32x2{-INFINITY, -INFINITY};
+        if (v0) { d0.x = lpi[j0] + load_e<ET>(E + j0); hist[j0] = d0.x; }
+        if (v1) { d0.y = lpi[j1] + load_e<ET>(E + j1); hist[j1] = d0.y; }
+        produce(d0, 0);
+    }
+    f32x2 er[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+        const ET* __restrict__ row = E + (size_t)(1 + k < Tb ? 1 + k : Tb - 1) * S;
+        er[k] = f32x2{load_e<ET>(row + jl0), load_e<ET>(row + jl1)};
+    }
+#pragma unroll
+    for (int w = 0; w < W; ++w) asm volatile("" ::"v"(aw0[w]), "v"(aw1[w]));
+#pragma unroll
+    for (int k = 0; k < NXL; ++k) asm volatile("" ::"v"(xa[k]));
+    asm volatile("" ::"v"(cj));
+    __syncthreads();
+
+    auto frame = [&](const int t, f32x2& e_slot, const int RB) {
+        const int WB = RB ^ 1;
+        const f32x4* __restrict__ win = reinterpret_cast<const f32x4*>(rp + RB * BUF);
+        float xd[NXL > 0 ? NXL : 1];
+#pragma unroll
+        for (int k = 0; k < NXL; ++k) xd[k] = dls[4 + sh + RB * BUF + xcol[k]];
+        const f32x4 wq = *reinterpret_cast<const f32x4*>(wm + RB * NWM);
+        f32x4 dw[W / 4];
+#pragma unroll
+        for (int q = 0; q < W / 4; ++q) dw[q] = win[q];
+        float m0 = -INFINITY, m1 = -INFINITY, n0 = -INFINITY, n1 = -INFINITY;   // two max3 chains per target
+#pragma unroll
+        for (int w = 0; w + 3 < W; w += 4) {
+            const f32x4 d = dw[w / 4];
+            const f32x2 a0 = f32x2{d.x, d.y} + f32x2{aw0[w + 0], aw0[w + 1]};
+            const f32x2 a1 = f32x2{d.z, d.w} + f32x2{aw0[w + 2], aw0[w + 3]};
+            const f32x2 b0 = f32x2{d.x, d.y} + f32x2{aw1[w + 0], aw1[w + 1]};
+            const f32x2 b1 = f32x2{d.z, d.w} + f32x2{aw1[w + 2], aw1[w + 3]};
+            m0 = fmaxf(fmaxf(m0, a0.x), a0.y);
+            n0 = fmaxf(fmaxf(n0, a1.x), a1.y);
+            m1 = fmaxf(fmaxf(m1, b0.x), b0.y);
+            n1 = fmaxf(fmaxf(n1, b1.x), b1.y);
         }
+        // M = max of delta_{t-1} over the non-extra sources; slots >= NPW of wq hold -inf
+        const float M = fmaxf(fmaxf(wq.x, wq.y), fmaxf(wq.z, wq.w));
+        const f32x2 fl = f32x2{M, M} + cj;
+        m0 = fmaxf(m0, fl.x);
+        m1 = fmaxf(m1, fl.y);
+#pragma unroll
+        for (int k = 0; k < NXL; ++k) {
+            const f32x2 xv = f32x2{xd[k], xd[k]} + xa[k];
+            n0 = fmaxf(n0, xv.x);
+            n1 = fmaxf(n1, xv.y);
+        }
+        const f32x2 dn = f32x2{fmaxf(m0, n0), fmaxf(m1, n1)} + e_slot;
+        produce(dn, WB);
+        asm volatile("" ::: "memory");   // history stores / prefetch behind the wave-max publication
+        const int tn = t + PF < Tb ? t + PF : Tb - 1;
+        float* __restrict__ hb = hist + (size_t)(t - 1) * SD;
+        const ET* __restrict__ erow = E + (size_t)tn * S;
+        hb[hoff0] = fm0 ? M : dn.x;
+        hb[hoff1] = fm1 ? M : dn.y;
+        e_slot = f32x2{load_e<ET>(erow + jl0), load_e<ET>(erow + jl1)};
         __syncthreads();
     };
+    const bool probe = (a.debug & 48) != 0;
+    const unsigned long long clk0 = probe ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long rt0 = probe ? __builtin_amdgcn_s_memrealtime() : 0ull;
     int t = 1;
-    for (; t + 1 < Tb; t += 2) {
-        frame(t, ea0, ea1);
-        frame(t + 1, eb0, eb1);
+    for (; t + PF - 1 < Tb; t += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) frame(t + k, er[k], k & 1);
     }
-    if (t < Tb) frame(t, ea0, ea1);
+#pragma unroll
+    for (int k = 0; k < PF - 1; ++k)
+        if (t + k < Tb) frame(t + k, er[k], k & 1);
 
-    // terminal state: lowest-index argmax of delta_{T-1}; a target lane holds two adjacent states
+    // terminal state: lowest-index argmax of delta_{T-1}; a lane holds two adjacent states
     {
+        const int fb = (Tb - 1) & 1;
+        const float* fin = dls + 4 + sh + fb * BUF;
         VI x = vi_identity();
-        if (v0) x = VI{dl[j0], j0};
-        if (v1) x = op_fwd(x, VI{dl[j1], j1});
+        if (v0) x = VI{fin[j0], j0};
+        if (v1) x = op_fwd(x, VI{fin[j1], j1});
         x = wave_scan<false>(x);
         if (lane == 63) tot[wv] = x;
         __syncthreads();
@@ -853,6 +856,10 @@ __global__ void __launch_bounds__(((NWT + 1) / 2 + 2) * 64) banded_pair_forward_
             a.last_state[song] = acc.i;
             if (a.loglik) a.loglik[song] = acc.v;
         }
+    }
+    if (probe && tid == 0 && a.loglik) {  // timing experiments only: cycles (16) or 100 MHz ticks (32) per frame
+        const unsigned long long d = (a.debug & 16) ? __builtin_amdgcn_s_memtime() - clk0 : __builtin_amdgcn_s_memrealtime() - rt0;
+        a.loglik[song] = (float)d / (float)(Tb > 1 ? Tb - 1 : 1);
     }
 }
 
@@ -1408,16 +1415,25 @@ hipError_t launch_dense(const FwdArgs& a, int ns, bool f16, hipStream_t st) {
 template <int W, int NWT, typename ET>
 static hipError_t launch_banded_t(const FwdArgs& a, hipStream_t st) {
     constexpr int NP = NWT * 64;
-    if (a.pair_ok && W <= 32 && (a.debug & 512)) {   // opt-in (VIT_DEBUG_FLAGS=512): measured slower, see DESIGN.md 4.1
-        constexpr int NPW = (NWT + 1) / 2;
-        const size_t lds = sizeof(float) * (NP + 2 * (NP + 1)) + sizeof(VI) * 16;
-        hipLaunchKernelGGL((banded_pair_forward_kernel<W, NWT, ET>), dim3((int)a.B), dim3((NPW + 2) * 64), lds, st, a);
-        return hipGetLastError();
-    }
-    if (a.floor_ok && a.S < NP && !(a.debug & ~(48 | 2048))) {   // 2048 only selects the generic back-trace   // one barrier, no scan waves (lane S stores the frame maximum: needs S < NP)
+    // Floor-max forms (plan.floor_ok; idle slot S stores the frame maximum: needs S < NP).  Up to two songs per CU the
+    // one-target-per-lane kernel is (slightly) faster; beyond that the two-targets-per-lane kernel wins because it moves
+    // half the window bytes through LDS (B = 512: 14.5 vs 15.5 ms).  VIT_DEBUG_FLAGS 512 / 1024 force one or the other.
+    if (a.floor_ok && a.S < NP && !(a.debug & ~(48 | 512 | 1024 | 2048)) && !((a.debug & 512) && (a.debug & 1024))) {
+        constexpr int PF = 4;   // emission rows in flight (2: 13.2 ms, 4: 11.2 ms, 8: 12.4 ms at B = 128)
+        if constexpr (W <= 32 && NWT <= 8) {
+            const bool pair = a.pair_ok && ((a.B > 256 && !(a.debug & 512)) || (a.debug & 1024));
+            if (pair) {
+                constexpr int NPW = (NWT + 1) / 2;
+                const size_t ldsp = sizeof(float) * (8 * (NPW * 128 + 16) + 2 * 4 + 64 + 4) + sizeof(VI) * 16;
+                if (W == 32 && a.n_extras == 1)
+                    hipLaunchKernelGGL((banded_floor_pair_forward_kernel<W, NPW, (W == 32 ? 1 : -1), PF, ET>), dim3((int)a.B), dim3(NPW * 64), ldsp, st, a);
+                else
+                    hipLaunchKernelGGL((banded_floor_pair_forward_kernel<W, NPW, -1, PF, ET>), dim3((int)a.B), dim3(NPW * 64), ldsp, st, a);
+                return hipGetLastError();
+            }
+        }
         constexpr int NWM = (NWT + 3) / 4 * 4;
         const size_t ldsf = sizeof(float) * (8 * (NP + 16) + 2 * NWM + 64 + NWM) + sizeof(VI) * 16;
-        constexpr int PF = 4;   // emission rows in flight (2: 13.2 ms, 4: 11.2 ms, 8: 12.4 ms at B = 128)
         if (W == 32 && a.n_extras == 1)   // the reference's matrices: band + unvoiced column
             hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, (W == 32 ? 1 : -1), PF, ET>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
         else

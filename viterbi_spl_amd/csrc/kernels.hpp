@@ -40,6 +40,9 @@ struct FwdArgs {
     size_t off_logpi, off_A4, off_lo, off_kind, off_tabA, off_extraA, off_denseA, off_rowc, off_lo2, off_tabP;
     int pair_ok;            // the plan proved pair windows: use the two-targets-per-lane kernel
     int floor_ok;           // the plan proved the one-maximum form (banded_floor_forward_kernel)
+    int win_shift2;         // the same for the pair windows of banded_floor_pair_forward_kernel
+    int win_shift;          // 0..3: delta is stored shifted by this many floats in LDS so that the window starts of a
+                            // 16-lane group are 16-byte aligned in the SAME copy order (bank-conflict-free b128 reads)
 };
 
 struct BtArgs {

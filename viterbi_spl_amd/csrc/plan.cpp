@@ -115,18 +115,23 @@ BandedPlan analyze_banded(const float* A, int S) {
             if (bp.kind[j] == -1) all = bp.lo[j] == std::max(0, std::min(j - off, S - W));
         if (all) { bp.lo_affine = true; bp.lo_off = off; }
     }
-    // pair windows: two adjacent targets evaluated by one lane over a common window of W + 2 sources
+    // pair windows: the exception spans of targets 2p and 2p+1 together fit ONE window of W sources, so one lane can
+    // evaluate both targets from a single set of window reads (half the LDS traffic per target)
     {
-        const int WP = W + 2;
         bp.lo2.assign(bp.SP / 2, 0);
-        bool ok = WP <= S && bp.n_dense == 0;
+        bool ok = bp.n_dense == 0;
         for (int p = 0; p < (S + 1) / 2 && ok; ++p) {
             const int j0 = 2 * p, j1 = std::min(2 * p + 1, S - 1);
             const int l = std::min(lo[j0], lo[j1]), h = std::max(hi[j0], hi[j1]);
-            if (h - l + 1 > WP) { ok = false; break; }
-            bp.lo2[p] = std::max(0, std::min(l, S - WP));
+            if (h - l + 1 > W) { ok = false; break; }
+            bp.lo2[p] = std::max(0, std::min(l, S - W));
         }
         bp.pair_ok = ok;
+        for (int off = 0; off <= 2 * W && ok && !bp.lo2_affine; ++off) {
+            bool all = true;
+            for (int p = 0; p < (S + 1) / 2 && all; ++p) all = bp.lo2[p] == std::max(0, std::min(2 * p - off, S - W));
+            if (all) { bp.lo2_affine = true; bp.lo2_off = off; }
+        }
     }
     // "floor-max" form: if no in-window entry of a banded row is below the row constant, the window term already
     // dominates fl(delta_i + c_j) for every in-window source i (rounding is monotone), so the out-of-window maximum
@@ -165,7 +170,7 @@ ImageLayout make_layout(int S, const BandedPlan& bp) {
     L.off_Arow = off;   off = align256(off + sizeof(float) * (size_t)S * L.SP);
     L.off_rowc = off;   off = align256(off + sizeof(float) * L.SP);
     L.off_lo2 = off;    off = align256(off + sizeof(int32_t) * L.SP);
-    L.off_tabP = off;   off = align256(off + sizeof(float) * (size_t)(std::max(L.W, 1) + 2) * L.SP);
+    L.off_tabP = off;   off = align256(off + sizeof(float) * (size_t)std::max(L.W, 1) * L.SP);
     L.bytes = off;
     return L;
 }
@@ -213,7 +218,7 @@ void fill_image(const float* A, const float* log_pi, const BandedPlan& bp, const
         int32_t* lo2 = reinterpret_cast<int32_t*>(image + L.off_lo2);
         float* tp = reinterpret_cast<float*>(image + L.off_tabP);
         for (int p = 0; p < SP / 2; ++p) lo2[p] = p < (int)bp.lo2.size() ? bp.lo2[p] : 0;
-        for (int w = 0; w < L.W + 2; ++w)
+        for (int w = 0; w < L.W; ++w)
             for (int j = 0; j < SP; ++j)
                 tp[(size_t)w * SP + j] = j < S ? A[(size_t)j * S + bp.lo2[j / 2] + w] : ninf;
     }

@@ -42,8 +42,10 @@ struct BandedPlan {
     bool lo_affine = false;   // lo[j] == clamp(j - lo_off, 0, S - W) for every banded row
     bool floor_ok = false;    // every non-extra window entry of every banded row is >= that row's constant, and no dense rows:
                               // then max_{i outside window} fl(delta_i + c_j) can be replaced by fl(max_{all non-extra i} delta_i + c_j)
-    bool pair_ok = false;     // targets (2p, 2p+1) share one window [lo2[p], lo2[p]+W+2) that covers both
+    bool pair_ok = false;     // targets (2p, 2p+1) share one window [lo2[p], lo2[p]+W) that covers both exception spans
     std::vector<int32_t> lo2; // [SP/2]
+    bool lo2_affine = false;  // lo2[p] == clamp(2p - lo2_off, 0, S - W)
+    int lo2_off = 0;
     int lo_off = 0;
 };
 
@@ -64,7 +66,7 @@ struct ImageLayout {
     size_t off_Arow = 0;     // float [S][SP]       row-major copy (row j = into target j) for the back-trace
     size_t off_rowc = 0;     // float [SP]          row constants c_j
     size_t off_lo2 = 0;      // int32 [SP/2]        pair windows (pair_ok)
-    size_t off_tabP = 0;     // float [W+2][SP]     tabP[w][j] = logA_T[j][lo2[j/2] + w]
+    size_t off_tabP = 0;     // float [W][SP]       tabP[w][j] = logA_T[j][lo2[j/2] + w]
     size_t bytes = 0;
 };
 

@@ -32,11 +32,11 @@ void vph_info(const vph_plan* p, int* info, float* c0) {
     info[15] = p->L.S4 | (p->bp.pair_ok ? 0x10000 : 0) | (p->bp.floor_ok ? 0x20000 : 0);
     *c0 = p->bp.c0;
 }
-// offsets[0..9]: logpi, A4, lo, kind, tabA, extraA, denseA, total bytes, Arow, rowc
+// offsets[0..11]: logpi, A4, lo, kind, tabA, extraA, denseA, total bytes, Arow, rowc, lo2, tabP
 void vph_offsets(const vph_plan* p, long long* off) {
     off[0] = p->L.off_logpi; off[1] = p->L.off_A4; off[2] = p->L.off_lo; off[3] = p->L.off_kind;
     off[4] = p->L.off_tabA; off[5] = p->L.off_extraA; off[6] = p->L.off_denseA; off[7] = p->L.bytes;
-    off[8] = p->L.off_Arow; off[9] = p->L.off_rowc;
+    off[8] = p->L.off_Arow; off[9] = p->L.off_rowc; off[10] = p->L.off_lo2; off[11] = p->L.off_tabP;
 }
 void vph_image(const vph_plan* p, unsigned char* out) { std::memcpy(out, p->image.data(), p->image.size()); }
 
