@@ -7,6 +7,14 @@ already resident in HBM, plus (N > 1) the RCCL gather of the decoded paths on ra
 Per-GPU work is fixed as N grows (weak scaling: 128 songs per GPU = BASELINE configs[2],
 and configs[3] = 1024 songs over 8 GPUs).
 
+The forward pass and the back-trace of a step run back to back on one HIP stream (overlapping the back-trace of
+step i with the forward pass of step i+1 on a second stream was measured: the HBM-bound back-trace slows the
+latency-bound forward pass from 10.6 to 13.7 ms, a net loss).  Only the gather (N > 1) is overlapped: it is
+launched non-blocking on the communicator's stream after the back-trace of step i and completes under the
+forward pass of step i+1; every batch in flight has its own workspace, path buffer and gather buffer (two
+slots).  The timed region ends with a device synchronisation and the completion of every gather.
+`--serial` waits for each gather before the next step starts.
+
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
@@ -49,6 +57,7 @@ def parse():
     ap.add_argument("--f16", action="store_true", help="store emissions as float16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--serial", action="store_true", help="no overlap between consecutive steps (one stream)")
     return ap.parse_args()
 
 
@@ -111,40 +120,77 @@ def main():
     gen = synth.emissions_peaks if args.emissions == "peaks" else synth.emissions_dense
     dt = torch.float16 if args.f16 else torch.float32
     E = gen(B, T, S, seed=1234, device=dev, dtype=dt, first_song=rank * B)
-    states = torch.empty((B, T), dtype=torch.int32, device=dev)
-    loglik = torch.empty((B,), dtype=torch.float32, device=dev)
     n_total = B * world
+    NSLOT = 2
+    states_k = [torch.empty((B, T), dtype=torch.int32, device=dev) for _ in range(NSLOT)]
+    loglik_k = [torch.empty((B,), dtype=torch.float32, device=dev) for _ in range(NSLOT)]
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"     # the latter: rehearse the gather path on one GPU
+    if use_dist and not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=dev)
+    if use_dist and rank == 0:
+        out_k = [(torch.empty((world, B, T), dtype=torch.int32, device=dev), torch.empty((world, B), dtype=torch.float32, device=dev))
+                 for _ in range(NSLOT)]
+    else:
+        out_k = [(None, None)] * NSLOT
+    pending = [None] * NSLOT
 
-    def step(ev=None):
+    def step(i, ev=None, overlap_gather=True):
+        """forward(i), back-trace(i) on the current stream; the gather of the paths on the communicator's stream."""
+        k = i % NSLOT
+        if pending[k] is not None:                     # gather(i - NSLOT) still reads states_k[k]
+            for w in pending[k]:
+                w.wait()
+            pending[k] = None
         if ev is not None:
             ev[0].record()
-        dec.decode_into(E, states, loglik, algo=algo, phase="forward")
+        dec.decode_into(E, states_k[k], loglik_k[k], algo=algo, phase="forward", slot=k)
         if ev is not None:
             ev[1].record()
-        dec.decode_into(E, states, loglik, algo=algo, phase="backtrace")
+        dec.decode_into(E, states_k[k], loglik_k[k], algo=algo, phase="backtrace", slot=k)
         if ev is not None:
             ev[2].record()
-        if world > 1:
-            return sharded.gather_paths(states, loglik, n_total, dst=0)
-        return states, loglik
+        if use_dist:
+            pending[k] = sharded.gather_paths_async(states_k[k], loglik_k[k], out_k[k][0], out_k[k][1], dst=0)
+            if not overlap_gather:
+                for w in pending[k]:
+                    w.wait()
+                pending[k] = None
 
-    for _ in range(args.warmup):
-        step()
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(events[k])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    def step_serial(i, ev=None):
+        step(i, ev, overlap_gather=False)
+
+    def drain():
+        for k in range(NSLOT):
+            if pending[k] is not None:
+                for w in pending[k]:
+                    w.wait()
+                pending[k] = None
+        torch.cuda.synchronize()
+
+    def timed(step_fn, n, with_events):
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)] if with_events else [None] * n
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            step_fn(i, evs[i])
+        drain()
+        if use_dist:
+            dist.barrier()
+        dt_ = time.perf_counter() - t0
+        if use_dist:
+            tmax = torch.tensor([dt_], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_ = float(tmax.item())
+        return dt_, evs
+
+    step_fn = step_serial if args.serial else step
+    for i in range(args.warmup):
+        step_fn(i)
+    drain()
+    elapsed, events = timed(step_fn, args.steps, True)
+    states, loglik = states_k[(args.steps - 1) % NSLOT], loglik_k[(args.steps - 1) % NSLOT]
 
     fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
     bt_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
@@ -185,7 +231,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"batch of {B} songs per GPU, T={T}, S={S}, {'fp16' if args.f16 else 'fp32'} log-emissions "
                                    f"(BASELINE configs[2]; configs[3] at 8 GPUs), forward + back-trace"
-                                   + (" + RCCL gather of paths" if world > 1 else ""),
+                                   + (" + RCCL gather of paths" if use_dist else ""),
                        "songs_per_gpu": B, "frames": T, "states": S, "emissions": args.emissions,
                        "transition": args.transition, "forward_kernel": algo, "plan": dec.info},
             "roofline": {"bound": "hbm", "kernel": fwd_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -196,6 +242,8 @@ def main():
                                  "implementation stores the float32 delta row instead (lazy back-pointers, DESIGN.md), "
                                  "and the recursion is fp32-VALU / latency bound, not HBM bound"},
             "kernels_ms": {"forward": fwd_ms, "backtrace": bt_ms},
+            "gather": (None if not use_dist else ("blocking (--serial)" if args.serial else
+                       "non-blocking on the communicator's stream, completes under the next step's forward pass; two path-buffer slots")),
             "backtrace": {"algorithmic_bytes_per_launch": bt_bytes, "traffic": bt_traffic,
                           "implementation_bytes_per_frame": SD * 4,
                           "hbm_gbs_from_traffic": (bt_traffic / (bt_ms * 1e-3) / 1e9) if bt_traffic else None},
@@ -203,14 +251,13 @@ def main():
             "whole_path_hbm_frac": value * 1e6 * (S * esize + S * 2 + 6) / 1e9 / (HBM_PEAK_GBS * world),
         }
         if world == 1 and not args.no_cpu_baseline:
-            step()
             torch.cuda.synchronize()
             cb, cbc = cpu_baseline(logA_T, log_pi, E, states, loglik, args.cpu_seconds)
             out["cpu_baseline"] = cb
             out["cpu_baseline_c"] = cbc
             out["gpu_over_cpu_1core"] = value / cb["value"]
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -190,7 +190,8 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
     if (algo == VIT_ALGO_BANDED) {
         e = vit::launch_banded(a, emis_dtype == VIT_F16, (hipStream_t)stream);
     } else {
-        const int ns = B >= 1024 ? 4 : (B >= 512 ? 2 : 1);
+        int ns = B >= 1024 ? 4 : (B >= 512 ? 2 : 1);
+        if (const char* e = std::getenv("VIT_DENSE_NS")) ns = std::atoi(e);   // timing experiments only
         e = vit::launch_dense(a, ns, emis_dtype == VIT_F16, (hipStream_t)stream);
     }
     return e == hipSuccess ? VIT_OK : hip_fail(e);

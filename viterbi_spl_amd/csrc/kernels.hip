@@ -1403,10 +1403,12 @@ static hipError_t launch_dense_t(const FwdArgs& a, hipStream_t st) {
 hipError_t launch_dense(const FwdArgs& a, int ns, bool f16, hipStream_t st) {
     while (ns > 1 && a.SP > dense_max_threads(ns)) ns >>= 1;
     if (f16) {
+        if (ns >= 8) return launch_dense_t<8, __half>(a, st);
         if (ns >= 4) return launch_dense_t<4, __half>(a, st);
         if (ns >= 2) return launch_dense_t<2, __half>(a, st);
         return launch_dense_t<1, __half>(a, st);
     }
+    if (ns >= 8) return launch_dense_t<8, float>(a, st);
     if (ns >= 4) return launch_dense_t<4, float>(a, st);
     if (ns >= 2) return launch_dense_t<2, float>(a, st);
     return launch_dense_t<1, float>(a, st);

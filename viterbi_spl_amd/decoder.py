@@ -73,6 +73,7 @@ class ViterbiDecoder:
             _lib.check(lib.vit_plan_upload(self._plan, self._image_ptr, nbytes, stream.cuda_stream), "vit_plan_upload")
             stream.synchronize()  # host image is pageable: make the copy visible before anything else
         self._ws: Optional[torch.Tensor] = None
+        self._ws_slots: dict = {}
 
     def __del__(self):
         try:
@@ -86,12 +87,23 @@ class ViterbiDecoder:
     def workspace_bytes(self, B: int, T: int) -> int:
         return int(_lib.load().vit_workspace_bytes(self._plan, B, T))
 
-    def _workspace(self, B: int, T: int) -> Tuple[int, int]:
+    def _workspace(self, B: int, T: int, slot: int = 0) -> Tuple[int, int]:
+        """Workspace `slot` (callers that overlap the back-trace of one batch with the forward pass of the next on
+        two streams give each batch in flight its own slot; slot 0 is the default)."""
         need = self.workspace_bytes(B, T)
-        if self._ws is None or self._ws.numel() < need + 256:
-            self._ws = None
-            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
-        return (self._ws.data_ptr() + 255) & ~255, need
+        ws = self._ws if slot == 0 else self._ws_slots.get(slot)
+        if ws is None or ws.numel() < need + 256:
+            ws = None
+            if slot == 0:
+                self._ws = None
+            else:
+                self._ws_slots.pop(slot, None)
+            ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            if slot == 0:
+                self._ws = ws
+            else:
+                self._ws_slots[slot] = ws
+        return (ws.data_ptr() + 255) & ~255, need
 
     # ------------------------------------------------------------------ checks
     def _check_emissions(self, logE: torch.Tensor) -> Tuple[torch.Tensor, bool, int]:
@@ -116,8 +128,9 @@ class ViterbiDecoder:
 
     # ------------------------------------------------------------------ decode
     def decode_into(self, logE: torch.Tensor, states: torch.Tensor, loglik: Optional[torch.Tensor] = None,
-                    lengths: Optional[torch.Tensor] = None, algo: str = "auto", phase: str = "both") -> None:
-        """Enqueue a decode on the current stream.  states: int32 [B,T]; loglik: float32 [B]."""
+                    lengths: Optional[torch.Tensor] = None, algo: str = "auto", phase: str = "both", slot: int = 0) -> None:
+        """Enqueue a decode on the current stream.  states: int32 [B,T]; loglik: float32 [B].
+        `phase` "forward" / "backtrace" run the two halves separately (same `slot` = same workspace)."""
         lib = _lib.load()
         logE, _, dt = self._check_emissions(logE)
         B, T, _ = logE.shape
@@ -128,7 +141,7 @@ class ViterbiDecoder:
         if lengths is not None:
             if lengths.dtype != torch.int64 or tuple(lengths.shape) != (B,) or lengths.device != self.device:
                 raise ValueError("lengths must be an int64 [B] tensor on the decoder's device")
-        ws_ptr, ws_bytes = self._workspace(B, T)
+        ws_ptr, ws_bytes = self._workspace(B, T, slot)
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
             len_ptr = lengths.data_ptr() if lengths is not None else None

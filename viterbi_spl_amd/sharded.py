@@ -53,6 +53,29 @@ def gather_paths(states_local: torch.Tensor, loglik_local: torch.Tensor, n_songs
     return states, loglik
 
 
+def gather_paths_async(states_local: torch.Tensor, loglik_local: torch.Tensor, out_states: Optional[torch.Tensor],
+                       out_loglik: Optional[torch.Tensor], dst: int = 0, group=None):
+    """Non-blocking gather for equal shards: rank ``dst`` passes ``out_states [world, b, T]`` / ``out_loglik [world, b]``
+    (reused from call to call; the shards land in place, no concatenation), the others pass None.  The collective is
+    ordered after the work already enqueued on the CURRENT stream and runs on the communicator's own stream, so the
+    caller can keep launching kernels (the next batch's forward pass) while the paths travel.  Returns the work
+    handles; ``wait()`` them (or synchronise the device) before reading the outputs or overwriting the inputs."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if rank == dst:
+        if out_states is None or out_loglik is None or out_states.shape[0] != world or out_loglik.shape[0] != world:
+            raise ValueError("destination rank needs out_states [world, b, T] and out_loglik [world, b]")
+        if tuple(out_states.shape[1:]) != tuple(states_local.shape) or tuple(out_loglik.shape[1:]) != tuple(loglik_local.shape):
+            raise ValueError("gather_paths_async needs equal shards")
+        list_s = [out_states[r] for r in range(world)]
+        list_l = [out_loglik[r] for r in range(world)]
+    else:
+        list_s = list_l = None
+    w1 = dist.gather(states_local, list_s, dst=dst, group=group, async_op=True)
+    w2 = dist.gather(loglik_local, list_l, dst=dst, group=group, async_op=True)
+    return w1, w2
+
+
 def decode_sharded(decode_fn: Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]],
                    emissions_local: torch.Tensor, n_songs: int, dst: int = 0, group=None):
     """Decode this rank's block of songs with ``decode_fn`` (e.g. ``ViterbiDecoder.decode``) and gather
