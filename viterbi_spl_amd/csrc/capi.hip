@@ -130,7 +130,9 @@ size_t vit_workspace_bytes(const vit_plan* plan, int64_t B, int64_t T) {
 }
 
 static int resolve_algo(const vit_plan* plan, int algo) {
-    const bool banded_possible = plan->bp.ok && vit::banded_target_waves(plan->S, plan->bp.W) > 0;
+    const int nwt = vit::banded_waves_for(plan->S);
+    const bool banded_possible = plan->bp.ok && (vit::scan_form_instantiated(plan->bp.W, nwt) ||
+                                                 (plan->bp.floor_ok && plan->S < nwt * 64 && vit::floor_form_instantiated(plan->bp.W, nwt)));
     if (algo == VIT_ALGO_AUTO) return banded_possible ? VIT_ALGO_BANDED : VIT_ALGO_DENSE;
     if (algo == VIT_ALGO_BANDED) return banded_possible ? VIT_ALGO_BANDED : VIT_EUNSUPPORTED;
     if (algo == VIT_ALGO_DENSE) return VIT_ALGO_DENSE;
@@ -239,6 +241,7 @@ int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* len
     b.off_kind = plan->L.off_kind;
     b.off_tabA = plan->L.off_tabA;
     b.off_extraA = plan->L.off_extraA;
+    b.off_tabX = plan->L.off_tabX;
     b.off_denseA = plan->L.off_denseA;
     b.off_Arow = plan->L.off_Arow;
     b.off_rowc = plan->L.off_rowc;

@@ -615,13 +615,20 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
         for (int q = 0; q < NWT / 4; ++q) wq[q] = reinterpret_cast<const f32x4*>(wm + RB * NWM)[q];
         if (NWT % 4 >= 2) wr = *reinterpret_cast<const f32x2*>(wm + RB * NWM + (NWT / 4) * 4);
         if (NWT % 4 == 1 || NWT % 4 == 3) wl = wm[RB * NWM + NWT - 1];
-        f32x4 dw[W / 4];
-#pragma unroll
-        for (int q = 0; q < W / 4; ++q) dw[q] = win[q];
+        // the window in chunks of 32 sources (8 reads): wide windows (W = 96, 128) must not hold all their data at once
         float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
 #pragma unroll
-        for (int w = 0; w + 7 < W; w += 8) {
-            const f32x4 da = dw[w / 4], db = dw[w / 4 + 1];
+        for (int w0 = 0; w0 < W; w0 += 32) {
+        // W > 64: one chunk of reads in flight at a time (W register-resident weights leave no room for more; with
+        // twelve waves per workgroup the other waves of the SIMD cover the read latency)
+        if ((W > 64 || (W == 64 && NWT > 8)) && w0 > 0) asm volatile("" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3)::"memory");
+        f32x4 dw[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (w0 + 4 * q < W) dw[q] = win[w0 / 4 + q];
+#pragma unroll
+        for (int w = w0; w + 7 < W && w < w0 + 32; w += 8) {
+            const f32x4 da = dw[(w - w0) / 4], db = dw[(w - w0) / 4 + 1];
             const f32x2 c0_ = f32x2{da.x, da.y} + f32x2{aw[w + 0], aw[w + 1]};
             const f32x2 c1_ = f32x2{da.z, da.w} + f32x2{aw[w + 2], aw[w + 3]};
             const f32x2 c2_ = f32x2{db.x, db.y} + f32x2{aw[w + 4], aw[w + 5]};
@@ -630,6 +637,7 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
             m1 = fmaxf(fmaxf(m1, c1_.x), c1_.y);
             m2 = fmaxf(fmaxf(m2, c2_.x), c2_.y);
             m3 = fmaxf(fmaxf(m3, c3_.x), c3_.y);
+        }
         }
         // M = max of delta_{t-1} over the non-extra sources
         float M = wl;
@@ -885,33 +893,35 @@ __device__ __forceinline__ void bt_fetch(f32x4 (&stage)[kBtVec], const f32x4* __
     }
 }
 
-template <int NWT, bool AFF, int MODE>
+// KC: candidate slots per lane (slot k of lane l holds candidate c = 64k + l; candidates: W window entries, then the
+// kMaxExtras extra-column entries, then the bound fl(M_t + c_j) formed from pad column S and the row constant).
+// GT: the per-target candidate table [SP][W+5] is read from the plan image in global memory (L2-resident) instead of
+// LDS -- at S = 722, W = 96 it is 310 KB and does not fit; a step then waits for one L2 access (~1 us) instead of an
+// LDS access, still far cheaper than evaluating whole matrix rows.
+template <int NWT, bool AFF, int MODE, int KC, bool GT>
 __global__ void __launch_bounds__(512) banded_backtrace_kernel(BtArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int EPL = NWT;               // sources per lane in the full evaluation, strided: i = e*64 + lane
     constexpr int TF = kBtVec * 256;       // floats per wave tile
     const int S = a.S, SP = a.SP, SD = a.SD, T = a.T, W = a.W, K = a.K;
     const int nx = a.n_extras;
-    const int WX = W + nx;                 // candidates held by lanes 0 .. WX-1 (WX <= 62)
-    const int WXS = W + kMaxExtras;
+    const int WX1 = W + kMaxExtras + 1;    // candidate-table row: window, extras, row constant
+    const int CB = W + kMaxExtras;         // candidate index of the bound
     const int nwaves = blockDim.x >> 6;
     const float* L = reinterpret_cast<const float*>(smem);          // all LDS indices below are float indices into L
     float* tiles = reinterpret_cast<float*>(smem);                  // [nwaves][TF]
-    float* rowcL = tiles + nwaves * TF;                             // [SP]
-    int32_t* loL = reinterpret_cast<int32_t*>(rowcL + SP);          // [SP]
-    float* tabX = reinterpret_cast<float*>(loL + SP);               // [SP][WXS]
+    int32_t* loL = reinterpret_cast<int32_t*>(tiles + nwaves * TF); // [SP]
+    float* tabX = reinterpret_cast<float*>(loL + SP);               // [SP][WX1] (LDS form only)
+    const float* __restrict__ gtab = reinterpret_cast<const float*>(a.image + a.off_tabX);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     {
         const int32_t* gl = reinterpret_cast<const int32_t*>(a.image + a.off_lo);
-        const float* gx = reinterpret_cast<const float*>(a.image + a.off_extraA);
-        const float* gt = reinterpret_cast<const float*>(a.image + a.off_tabA);
-        const float* gc = reinterpret_cast<const float*>(a.image + a.off_rowc);
         const int nthr = blockDim.x;
-        for (int k = tid; k < SP; k += nthr) { loL[k] = gl[k]; rowcL[k] = gc[k]; }
-        for (int k = tid; k < W * SP; k += nthr) tabX[(k % SP) * WXS + k / SP] = gt[k];
-        for (int k = tid; k < kMaxExtras * SP; k += nthr) tabX[(k % SP) * WXS + W + k / SP] = gx[k];
+        for (int k = tid; k < SP; k += nthr) loL[k] = gl[k];
+        if (!GT)
+            for (int k = tid; k < SP * WX1; k += nthr) tabX[k] = gtab[k];
     }
     __syncthreads();
 
@@ -926,14 +936,23 @@ __global__ void __launch_bounds__(512) banded_backtrace_kernel(BtArgs a) {
     float* tile = tiles + wv * TF;
     const int tile_off = wv * TF;
 
-    // ---- per-lane constants
-    const bool isw = lane < W;
-    const int xs = (lane >= W && lane < WX) ? a.extras[(lane - W) & (kMaxExtras - 1)] : 0;
-    const int pb = lane == 63 ? S : (isw ? lane : xs);                       // row entry read by this lane (window lanes: + lo)
-    const int tb = lane == 63 ? (int)(rowcL - tiles) : (int)(tabX - tiles) + (lane < WXS ? lane : WXS - 1);
-    const int ts = lane == 63 ? 1 : WXS;                                    // table index = tb + state * ts
-    const bool cand = lane < WX;
-    const unsigned long long wmask = (1ull << W) - 1ull;                    // W <= 32 here
+    // ---- per-lane constants, per candidate slot
+    bool isw[KC], cand[KC];
+    int pb[KC], tb[KC];
+    unsigned long long wmask[KC];                                           // lanes of slot k that hold window candidates
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        const int c = 64 * k + lane;
+        isw[k] = c < W;
+        cand[k] = c < W + nx;
+        const int xs = (c >= W && c < W + nx) ? a.extras[(c - W) & (kMaxExtras - 1)] : 0;
+        pb[k] = c == CB ? S : (isw[k] ? c : xs);                             // row entry read (window candidates: + lo)
+        tb[k] = c < WX1 ? c : WX1 - 1;                                       // entry of the target's table row
+        const int nwin = W - 64 * k;
+        wmask[k] = nwin >= 64 ? ~0ull : (nwin <= 0 ? 0ull : ((1ull << nwin) - 1ull));
+    }
+    const int kb = CB >> 6, lb = CB & 63;                                    // slot / lane of the bound candidate
+    const int tabX_off = (int)(tabX - tiles);
     int ic[EPL];
     bool isx[EPL], inS[EPL];
 #pragma unroll
@@ -978,28 +997,56 @@ __global__ void __launch_bounds__(512) banded_backtrace_kernel(BtArgs a) {
                 } else {
                     lo = __builtin_amdgcn_readfirstlane(loL[cur]);
                 }
-                const float dv = L[row_off + pb + (isw ? lo : 0)];
-                const float av = L[tb + (int)__umul24((unsigned)cur, (unsigned)ts)];
-                const float vall = dv + av;
-                // lane 63: fl(max_i delta_t[i] + c_cur), the bound on every row-constant candidate
-                const float mf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vall), 63));
-                const float v = cand ? vall : -INFINITY;
-                const float m = wave_max_all(v);
+                float v[KC], av[KC];
+#pragma unroll
+                for (int k = 0; k < KC; ++k) {
+                    const float dv = L[row_off + pb[k] + (isw[k] ? lo : 0)];
+                    av[k] = GT ? gtab[(size_t)cur * WX1 + tb[k]] : L[tabX_off + (int)__umul24((unsigned)cur, (unsigned)WX1) + tb[k]];
+                    v[k] = dv + av[k];
+                }
+                // the bound candidate: fl(max_i delta_t[i] + c_cur), on every row-constant candidate
+                float mf = 0.f, cj = 0.f;
+#pragma unroll
+                for (int k = 0; k < KC; ++k)
+                    if (k == kb) {
+                        mf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), lb));
+                        cj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(av[k]), lb));
+                    }
+                float mloc = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < KC; ++k) {
+                    v[k] = cand[k] ? v[k] : -INFINITY;
+                    mloc = fmaxf(mloc, v[k]);
+                }
+                const float m = wave_max_all(mloc);
+                // lowest source index among the window / extra-column candidates equal to `mm`
+                auto lowest_candidate = [&](const float mm) -> unsigned {
+                    unsigned best = 0x7fffffffu;
+                    bool have_w = false;
+#pragma unroll
+                    for (int k = 0; k < KC; ++k) {
+                        const unsigned long long mk = __ballot(v[k] == mm && cand[k]);
+                        const unsigned long long mw = mk & wmask[k];
+                        if (mw && !have_w) {                                 // window candidates ascend with the source index
+                            const unsigned c = lo + 64 * k + __builtin_ctzll(mw);
+                            best = c < best ? c : best;
+                            have_w = true;
+                        }
+                        unsigned long long mx = mk & ~wmask[k];              // extra-column candidates: arbitrary indices
+                        while (mx) {
+                            const unsigned c = __builtin_amdgcn_readlane(pb[k], __builtin_ctzll(mx));
+                            best = c < best ? c : best;
+                            mx &= mx - 1;
+                        }
+                    }
+                    return best;
+                };
                 unsigned idx = 0x7fffffffu;
                 if (mf < m) {
                     // ---- common case: no row-constant candidate can tie or win
-                    const unsigned long long mk = __ballot(v == m);
-                    const unsigned long long mw = mk & wmask;
-                    if (mw) idx = lo + __builtin_ctzll(mw);                  // window lanes ascend with the source index
-                    unsigned mx = (unsigned)(mk >> W) & ((1u << kMaxExtras) - 1u);
-                    while (mx) {                                             // extra-column lanes: arbitrary indices
-                        const unsigned c = __builtin_amdgcn_readlane(pb, W + __builtin_ctz(mx));
-                        idx = c < idx ? c : idx;
-                        mx &= mx - 1;
-                    }
+                    idx = lowest_candidate(m);
                 } else {
                     // ---- full evaluation: every source outside the window / extras contributes fl(delta_t[i] + c_cur)
-                    const float cj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(av), 63));
                     float vf[EPL];
                     float m2 = -INFINITY;
 #pragma unroll
@@ -1018,15 +1065,8 @@ __global__ void __launch_bounds__(512) banded_backtrace_kernel(BtArgs a) {
                         const unsigned long long mk = __ballot(vf[e] == mm && inS[e]);
                         if (mk) { const unsigned c = e * 64 + __builtin_ctzll(mk); idx = c < idx ? c : idx; }
                     }
-                    const unsigned long long mk = __ballot(v == mm && cand);
-                    const unsigned long long mw = mk & wmask;
-                    if (mw) { const unsigned c = lo + __builtin_ctzll(mw); idx = c < idx ? c : idx; }
-                    unsigned mx = (unsigned)(mk >> W) & ((1u << kMaxExtras) - 1u);
-                    while (mx) {
-                        const unsigned c = __builtin_amdgcn_readlane(pb, W + __builtin_ctz(mx));
-                        idx = c < idx ? c : idx;
-                        mx &= mx - 1;
-                    }
+                    const unsigned c = lowest_candidate(mm);
+                    idx = c < idx ? c : idx;
                     if (idx == 0x7fffffffu) idx = 0;
                 }
                 cur = (int)idx;
@@ -1414,34 +1454,39 @@ hipError_t launch_dense(const FwdArgs& a, int ns, bool f16, hipStream_t st) {
     return launch_dense_t<1, float>(a, st);
 }
 
+// floor-max forms (plan.floor_ok; idle slot S stores the frame maximum: needs S < 64 * NWT)
 template <int W, int NWT, typename ET>
-static hipError_t launch_banded_t(const FwdArgs& a, hipStream_t st) {
+static hipError_t launch_floor_t(const FwdArgs& a, hipStream_t st) {
     constexpr int NP = NWT * 64;
-    // Floor-max forms (plan.floor_ok; idle slot S stores the frame maximum: needs S < NP).  Up to two songs per CU the
-    // one-target-per-lane kernel is (slightly) faster; beyond that the two-targets-per-lane kernel wins because it moves
-    // half the window bytes through LDS (B = 512: 14.5 vs 15.5 ms).  VIT_DEBUG_FLAGS 512 / 1024 force one or the other.
-    if (a.floor_ok && a.S < NP && !(a.debug & ~(48 | 512 | 1024 | 2048)) && !((a.debug & 512) && (a.debug & 1024))) {
-        constexpr int PF = 4;   // emission rows in flight (2: 13.2 ms, 4: 11.2 ms, 8: 12.4 ms at B = 128)
-        if constexpr (W <= 32 && NWT <= 8) {
-            const bool pair = a.pair_ok && ((a.B > 256 && !(a.debug & 512)) || (a.debug & 1024));
-            if (pair) {
-                constexpr int NPW = (NWT + 1) / 2;
-                const size_t ldsp = sizeof(float) * (8 * (NPW * 128 + 16) + 2 * 4 + 64 + 4) + sizeof(VI) * 16;
-                if (W == 32 && a.n_extras == 1)
-                    hipLaunchKernelGGL((banded_floor_pair_forward_kernel<W, NPW, (W == 32 ? 1 : -1), PF, ET>), dim3((int)a.B), dim3(NPW * 64), ldsp, st, a);
-                else
-                    hipLaunchKernelGGL((banded_floor_pair_forward_kernel<W, NPW, -1, PF, ET>), dim3((int)a.B), dim3(NPW * 64), ldsp, st, a);
-                return hipGetLastError();
-            }
+    constexpr int PF = 4;   // emission rows in flight (2: 13.2 ms, 4: 11.2 ms, 8: 12.4 ms at B = 128)
+    // Up to two songs per CU the one-target-per-lane kernel is (slightly) faster; beyond that the two-targets-per-lane
+    // kernel wins because it moves half the window bytes through LDS (B = 512: 14.5 vs 15.5 ms).
+    // VIT_DEBUG_FLAGS 512 / 1024 force one or the other.
+    if constexpr (W <= 32 && NWT <= 8) {
+        const bool pair = a.pair_ok && ((a.B > 256 && !(a.debug & 512)) || (a.debug & 1024));
+        if (pair) {
+            constexpr int NPW = (NWT + 1) / 2;
+            const size_t ldsp = sizeof(float) * (8 * (NPW * 128 + 16) + 2 * 4 + 64 + 4) + sizeof(VI) * 16;
+            if (W == 32 && a.n_extras == 1)
+                hipLaunchKernelGGL((banded_floor_pair_forward_kernel<W, NPW, (W == 32 ? 1 : -1), PF, ET>), dim3((int)a.B), dim3(NPW * 64), ldsp, st, a);
+            else
+                hipLaunchKernelGGL((banded_floor_pair_forward_kernel<W, NPW, -1, PF, ET>), dim3((int)a.B), dim3(NPW * 64), ldsp, st, a);
+            return hipGetLastError();
         }
-        constexpr int NWM = (NWT + 3) / 4 * 4;
-        const size_t ldsf = sizeof(float) * (8 * (NP + 16) + 2 * NWM + 64 + NWM) + sizeof(VI) * 16;
-        if (W == 32 && a.n_extras == 1)   // the reference's matrices: band + unvoiced column
-            hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, (W == 32 ? 1 : -1), PF, ET>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
-        else
-            hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, -1, PF, ET>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
-        return hipGetLastError();
     }
+    constexpr int NWM = (NWT + 3) / 4 * 4;
+    const size_t ldsf = sizeof(float) * (8 * (NP + 16) + 2 * NWM + 64 + NWM) + sizeof(VI) * 16;
+    if ((W == 32 || W >= 96) && a.n_extras == 1)   // the reference's matrices: band + unvoiced column (compile-time extras count)
+        hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, ((W == 32 || W >= 96) ? 1 : -1), PF, ET>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
+    else
+        hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, -1, PF, ET>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
+    return hipGetLastError();
+}
+
+// general (scan) form
+template <int W, int NWT, typename ET>
+static hipError_t launch_scan_t(const FwdArgs& a, hipStream_t st) {
+    constexpr int NP = NWT * 64;
     const size_t lds = sizeof(float) * (4 * (NP + 16) + 2 * (NP + 1) + kMaxDenseRows) + sizeof(VI) * 16;
     // NWT + 2 waves put exactly two on each SIMD at S = 361 and let two workgroups share a CU.  Only a
     // plan with dense rows, run at one workgroup per CU, gets a separate wave for them (it would
@@ -1459,25 +1504,28 @@ static hipError_t launch_banded_t(const FwdArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+template <int W, int NWT, typename ET>
+static hipError_t launch_banded_t(const FwdArgs& a, hipStream_t st) {
+    // VIT_DEBUG_FLAGS: 48 cycle probes, 512 / 1024 choose between the floor kernels, 2048 only selects the generic
+    // back-trace; anything else (4096: "scan form", the ablation bits) goes to the general kernel
+    const bool floor_ok = a.floor_ok && a.S < NWT * 64 && !(a.debug & ~(48 | 512 | 1024 | 2048)) &&
+                          !((a.debug & 512) && (a.debug & 1024));
+    if constexpr (floor_form_instantiated(W, NWT)) {
+        if (floor_ok) return launch_floor_t<W, NWT, ET>(a, st);
+    }
+    if constexpr (scan_form_instantiated(W, NWT)) return launch_scan_t<W, NWT, ET>(a, st);
+    return hipErrorInvalidConfiguration;
+}
+
 template <int W, typename ET>
 static hipError_t launch_banded_w(const FwdArgs& a, hipStream_t st) {
-    const int nwt = banded_target_waves(a.S, W);
-    if constexpr (W <= 32) {
-        switch (nwt) {
-            case 2: return launch_banded_t<W, 2, ET>(a, st);
-            case 4: return launch_banded_t<W, 4, ET>(a, st);
-            case 6: return launch_banded_t<W, 6, ET>(a, st);
-            case 8: return launch_banded_t<W, 8, ET>(a, st);
-            case 12: return launch_banded_t<W, 12, ET>(a, st);
-            default: return hipErrorInvalidConfiguration;
-        }
-    } else {
-        switch (nwt) {
-            case 2: return launch_banded_t<W, 2, ET>(a, st);
-            case 4: return launch_banded_t<W, 4, ET>(a, st);
-            case 6: return launch_banded_t<W, 6, ET>(a, st);
-            default: return hipErrorInvalidConfiguration;
-        }
+    switch (banded_waves_for(a.S)) {
+        case 2: return launch_banded_t<W, 2, ET>(a, st);
+        case 4: return launch_banded_t<W, 4, ET>(a, st);
+        case 6: return launch_banded_t<W, 6, ET>(a, st);
+        case 8: return launch_banded_t<W, 8, ET>(a, st);
+        case 12: return launch_banded_t<W, 12, ET>(a, st);
+        default: return hipErrorInvalidConfiguration;
     }
 }
 
@@ -1487,6 +1535,8 @@ static hipError_t launch_banded_e(const FwdArgs& a, hipStream_t st) {
         case 16: return launch_banded_w<16, ET>(a, st);
         case 32: return launch_banded_w<32, ET>(a, st);
         case 64: return launch_banded_w<64, ET>(a, st);
+        case 96: return launch_banded_w<96, ET>(a, st);
+        case 128: return launch_banded_w<128, ET>(a, st);
         default: return hipErrorInvalidConfiguration;
     }
 }
@@ -1502,25 +1552,38 @@ int backtrace_tile_rows(int SD) {
 
 constexpr size_t kLdsBytes = 160 * 1024;
 
-template <int NWT, bool AFF>
+template <int NWT, bool AFF, int KC, bool GT>
 static hipError_t launch_bt_lean(const BtArgs& a, int nwaves, size_t lds, hipStream_t st) {
     const long long waves0 = (long long)a.B * a.chunks;
-    hipLaunchKernelGGL((banded_backtrace_kernel<NWT, AFF, 0>), dim3((int)((waves0 + nwaves - 1) / nwaves)), dim3(nwaves * 64), lds, st, a);
+    hipLaunchKernelGGL((banded_backtrace_kernel<NWT, AFF, 0, KC, GT>), dim3((int)((waves0 + nwaves - 1) / nwaves)), dim3(nwaves * 64), lds, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || a.chunks <= 1) return e;
-    hipLaunchKernelGGL((banded_backtrace_kernel<NWT, AFF, 1>), dim3((int)((a.B + nwaves - 1) / nwaves)), dim3(nwaves * 64), lds, st, a);
+    hipLaunchKernelGGL((banded_backtrace_kernel<NWT, AFF, 1, KC, GT>), dim3((int)((a.B + nwaves - 1) / nwaves)), dim3(nwaves * 64), lds, st, a);
     return hipGetLastError();
+}
+
+template <int NWT, int KC, bool GT>
+static hipError_t launch_bt_lean_a(const BtArgs& a, int nwaves, size_t lds, hipStream_t st) {
+    return a.lo_affine ? launch_bt_lean<NWT, true, KC, GT>(a, nwaves, lds, st) : launch_bt_lean<NWT, false, KC, GT>(a, nwaves, lds, st);
 }
 
 template <int NWT>
 static hipError_t launch_bt_t(BtArgs a, hipStream_t st) {
-    // lean kernel: banded plan, no dense rows, frame maxima stored by the forward pass, candidates fit lanes 0..61
-    if (a.banded && a.have_fmax && a.n_dense == 0 && a.W <= 32 && a.W + a.n_extras <= 62 && !(a.debug & 2048)) {
-        const size_t tables = sizeof(float) * a.SP * (2 + a.W + kMaxExtras);
-        for (int nw = 8; nw >= 1; nw >>= 1) {
-            const size_t lds = sizeof(f32x4) * kBtVec * 64 * nw + tables;
-            if (lds + 1024 > kLdsBytes) continue;
-            return a.lo_affine ? launch_bt_lean<NWT, true>(a, nw, lds, st) : launch_bt_lean<NWT, false>(a, nw, lds, st);
+    // lean kernel: banded plan, no dense rows, frame maxima stored by the forward pass
+    if constexpr (NWT <= 12) {
+        if (a.banded && a.have_fmax && a.n_dense == 0 && a.W <= 128 && !(a.debug & 2048)) {
+            const int kc = (a.W + kMaxExtras + 1 + 63) / 64;
+            const size_t tile = sizeof(f32x4) * kBtVec * 64, lo_tab = sizeof(int32_t) * a.SP;
+            const size_t table = sizeof(float) * (size_t)a.SP * (a.W + kMaxExtras + 1);
+            // candidate table in LDS when it leaves room for at least four waves, else read from the image (L2)
+            if (kc == 1 && 4 * tile + lo_tab + table + 1024 <= kLdsBytes) {
+                const int nw = 8 * tile + lo_tab + table + 1024 <= kLdsBytes ? 8 : 4;
+                return launch_bt_lean_a<NWT, 1, false>(a, nw, nw * tile + lo_tab + table, st);
+            }
+            const size_t lds = 8 * tile + lo_tab;
+            if (kc == 1) return launch_bt_lean_a<NWT, 1, true>(a, 8, lds, st);
+            if (kc == 2) return launch_bt_lean_a<NWT, 2, true>(a, 8, lds, st);
+            if (kc == 3) return launch_bt_lean_a<NWT, 3, true>(a, 8, lds, st);
         }
     }
     size_t lds = sizeof(f32x4) * kBtWaves * kBtVec * 64 + sizeof(int32_t) * kBtWaves * 64;

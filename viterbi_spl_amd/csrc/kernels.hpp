@@ -8,16 +8,23 @@
 
 namespace vit {
 
-// Banded kernel geometry: NWT target waves (64*NWT >= S) plus two scan waves.  Returns the
-// number of target waves for (S, W), or 0 when the combination is not instantiated
-// (W register-resident transition entries per thread bound the workgroup size).
-constexpr int banded_target_waves(int S, int W) {
+// Banded kernel geometry: NWT target waves (64*NWT >= S), NWT in {2,4,6,8,12}.  Which (W, NWT) combinations are
+// instantiated is bounded by registers: W window entries stay register-resident per thread.
+//   scan form  (banded_forward_kernel: + two scan waves)      W <= 32: NWT <= 12;  W == 64: NWT <= 6
+//   floor form (banded_floor_forward_kernel, plan.floor_ok)   W <= 96: NWT <= 12;  W == 128: NWT <= 8
+constexpr int banded_waves_for(int S) {
     const int need = (S + 63) / 64;
     const int opts[5] = {2, 4, 6, 8, 12};
-    const int nopts = W <= 32 ? 5 : (W <= 64 ? 3 : 0);
-    for (int k = 0; k < nopts; ++k)
+    for (int k = 0; k < 5; ++k)
         if (opts[k] >= need) return opts[k];
     return 0;
+}
+constexpr bool scan_form_instantiated(int W, int nwt) { return nwt > 0 && ((W <= 32 && nwt <= 12) || (W == 64 && nwt <= 6)); }
+constexpr bool floor_form_instantiated(int W, int nwt) { return nwt > 0 && ((W <= 96 && nwt <= 12) || (W == 128 && nwt <= 8)); }
+// target waves of the scan form for (S, W), or 0 when it is not instantiated
+constexpr int banded_target_waves(int S, int W) {
+    const int nwt = banded_waves_for(S);
+    return scan_form_instantiated(W, nwt) ? nwt : 0;
 }
 // the dense kernel keeps NS running (best, arg) pairs per thread
 constexpr int dense_max_threads(int NS) { return NS <= 2 ? 1024 : 512; }
@@ -63,7 +70,7 @@ struct BtArgs {
     int n_extras, n_dense;
     int extras[kMaxExtras];
     float c0;
-    size_t off_lo, off_kind, off_tabA, off_extraA, off_denseA, off_Arow, off_rowc;
+    size_t off_lo, off_kind, off_tabA, off_extraA, off_denseA, off_Arow, off_rowc, off_tabX;
 };
 
 hipError_t launch_dense(const FwdArgs& a, int songs_per_group, bool f16, hipStream_t st);

@@ -17,7 +17,7 @@ static inline uint32_t f2u(float f) {
 
 static inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
-static const int kWidths[] = {16, 32, 64};  // window widths the banded kernel is instantiated for
+static const int kWidths[] = {16, 32, 64, 96, 128};  // window widths the banded kernels are instantiated for
 
 BandedPlan analyze_banded(const float* A, int S) {
     BandedPlan bp;
@@ -65,10 +65,8 @@ BandedPlan analyze_banded(const float* A, int S) {
         return false;
     };
 
-    // 3. per-row exception windows; rows whose exceptions do not fit a window become dense rows
+    // 3. per-row exception spans
     std::vector<int> lo(S, 0), hi(S, 0);
-    std::vector<int> dense;
-    int max_window = 1;
     for (int j = 0; j < S; ++j) {
         int l = S, h = -1;
         for (int i = 0; i < S; ++i) {
@@ -77,21 +75,29 @@ BandedPlan analyze_banded(const float* A, int S) {
             h = std::max(h, i);
         }
         if (h < l) { l = h = std::min(j, S - 1); }
-        if (h - l + 1 > kMaxWindow) { dense.push_back(j); continue; }
         lo[j] = l;
         hi[j] = h;
-        max_window = std::max(max_window, h - l + 1);
     }
-    if ((int)dense.size() > kMaxDenseRows) return bp;
+
+    // 4. evaluated window width: the narrowest instantiated width that leaves at most kMaxDenseRows rows outside
+    //    (those become "dense rows": a full max over every source) and still beats the dense kernel (2W <= S)
+    int W = 0;
+    for (int w : kWidths) {
+        int outliers = 0;
+        for (int j = 0; j < S; ++j) outliers += (hi[j] - lo[j] + 1 > w);
+        if (outliers <= kMaxDenseRows && w <= S && 2 * w <= S) { W = w; break; }
+    }
+    if (W == 0) return bp;
+    bp.W = W;
+    std::vector<int> dense;
+    int max_window = 1;
+    for (int j = 0; j < S; ++j) {
+        if (hi[j] - lo[j] + 1 > W) { dense.push_back(j); continue; }
+        max_window = std::max(max_window, hi[j] - lo[j] + 1);
+    }
     bp.n_dense = (int)dense.size();
     for (int d = 0; d < bp.n_dense; ++d) bp.dense_rows[d] = dense[d];
     bp.max_window = max_window;
-
-    // 4. evaluated window width
-    int W = 0;
-    for (int w : kWidths) if (w >= max_window) { W = w; break; }
-    if (W == 0 || W > S || 2 * W > S) return bp;  // too wide to beat the dense kernel
-    bp.W = W;
 
     for (int j = 0; j < S; ++j) {
         bp.kind[j] = -1;
@@ -171,6 +177,7 @@ ImageLayout make_layout(int S, const BandedPlan& bp) {
     L.off_rowc = off;   off = align256(off + sizeof(float) * L.SP);
     L.off_lo2 = off;    off = align256(off + sizeof(int32_t) * L.SP);
     L.off_tabP = off;   off = align256(off + sizeof(float) * (size_t)std::max(L.W, 1) * L.SP);
+    L.off_tabX = off;   off = align256(off + sizeof(float) * (size_t)(std::max(L.W, 1) + kMaxExtras + 1) * L.SP);
     L.bytes = off;
     return L;
 }
@@ -214,6 +221,18 @@ void fill_image(const float* A, const float* log_pi, const BandedPlan& bp, const
         for (int j = 0; j < S; ++j) xa[(size_t)k * SP + j] = A[(size_t)j * S + bp.extras[k]];
     for (int d = 0; d < bp.n_dense; ++d)
         for (int i = 0; i < S; ++i) da[(size_t)d * SP + i] = A[(size_t)bp.dense_rows[d] * S + i];
+    {   // per-target candidate rows for the back-trace: window, extra columns (-inf beyond n_extras), row constant
+        const int WX1 = L.W + kMaxExtras + 1;
+        float* tx = reinterpret_cast<float*>(image + L.off_tabX);
+        for (int j = 0; j < SP; ++j) {
+            float* row = tx + (size_t)j * WX1;
+            for (int c = 0; c < WX1; ++c) row[c] = ninf;
+            if (j >= S) continue;
+            for (int w = 0; w < L.W; ++w) row[w] = A[(size_t)j * S + bp.lo[j] + w];
+            for (int k = 0; k < bp.n_extras; ++k) row[L.W + k] = A[(size_t)j * S + bp.extras[k]];
+            row[L.W + kMaxExtras] = bp.rowc[j];
+        }
+    }
     if (bp.pair_ok) {
         int32_t* lo2 = reinterpret_cast<int32_t*>(image + L.off_lo2);
         float* tp = reinterpret_cast<float*>(image + L.off_tabP);

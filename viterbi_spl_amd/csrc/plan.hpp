@@ -23,7 +23,7 @@ namespace vit {
 
 constexpr int kMaxExtras = 4;
 constexpr int kMaxDenseRows = 4;
-constexpr int kMaxWindow = 64;   // widest window the banded kernel is instantiated for
+constexpr int kMaxWindow = 128;  // widest window the banded kernels are instantiated for (jdc: d_max 40 -> 82, imm: 56 -> 114)
 
 struct BandedPlan {
     bool ok = false;          // the decomposition was proven for this matrix
@@ -36,7 +36,7 @@ struct BandedPlan {
     int n_dense = 0;
     int dense_rows[kMaxDenseRows] = {0, 0, 0, 0};
     int max_window = 0;       // widest proven exception window among banded rows
-    int W = 0;                // window width the kernel evaluates (16/32/64/128)
+    int W = 0;                // window width the kernel evaluates (16/32/64/96/128)
     std::vector<int32_t> lo;  // [SP] first source of the evaluated window (lo + W <= S)
     std::vector<int32_t> kind;// [SP] -1 banded row, d >= 0 dense row d, -2 padding
     bool lo_affine = false;   // lo[j] == clamp(j - lo_off, 0, S - W) for every banded row
@@ -67,6 +67,7 @@ struct ImageLayout {
     size_t off_rowc = 0;     // float [SP]          row constants c_j
     size_t off_lo2 = 0;      // int32 [SP/2]        pair windows (pair_ok)
     size_t off_tabP = 0;     // float [W][SP]       tabP[w][j] = logA_T[j][lo2[j/2] + w]
+    size_t off_tabX = 0;     // float [SP][W+5]     per target: W window entries, 4 extra-column entries, row constant (back-trace)
     size_t bytes = 0;
 };
 
