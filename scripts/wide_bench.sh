@@ -1,7 +1,7 @@
 #!/bin/bash
 # high-resolution grid (BASELINE configs[4]): S = 722, fp16 emissions, B = 256, wide bands
 cd "$(dirname "$0")/.."
-for dm in 14 30 40; do python - <<PY
+for dm in 14 30 40 56; do python - <<PY
 import sys, torch
 sys.path.insert(0, ".")
 from viterbi_spl_amd import ViterbiDecoder, synth

@@ -521,6 +521,10 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
     float* wm = dls + 2 * BUF;                    // [2][NWM]
     float* dump = wm + 2 * NWM;                   // [64 + NWM] per-lane dump slots (lanes that do not own a wave max)
     VI* tot = reinterpret_cast<VI*>(dump + 64 + NWM);
+    // W = 128 with twelve waves (S > 512) leaves 168 registers per thread: the last 32 window weights then live in LDS
+    // ([8][NP] float4-interleaved, read with conflict-free 16-byte reads next to the delta window)
+    constexpr int WR = (W == 128 && NWT > 8) ? 96 : W;     // register-resident window weights
+    f32x4* awl = reinterpret_cast<f32x4*>(tot + 16);       // [(W - WR) / 4][NP]
     const int S = a.S, SP = a.SP, T = a.T, SD = a.SD;
     constexpr bool GEN = NXT < 0;
     constexpr int NXL = GEN ? kMaxExtras : NXT;
@@ -545,7 +549,7 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
     const bool is_fm = j == S;
     const int lo = reinterpret_cast<const int32_t*>(a.image + a.off_lo)[jc];
     const float cj = tvalid ? reinterpret_cast<const float*>(a.image + a.off_rowc)[jc] : -INFINITY;
-    float aw[W];
+    float aw[WR];
     float xa[NXL > 0 ? NXL : 1];
     int xcol[NXL > 0 ? NXL : 1];
     bool is_x = false;                                                    // this lane's state is an extra column: not part of M
@@ -553,7 +557,16 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
         const float* __restrict__ tab = reinterpret_cast<const float*>(a.image + a.off_tabA);
         const float* __restrict__ xaT = reinterpret_cast<const float*>(a.image + a.off_extraA);
 #pragma unroll
-        for (int w = 0; w < W; ++w) aw[w] = tvalid ? tab[(size_t)w * SP + jc] : -INFINITY;
+        for (int w = 0; w < WR; ++w) aw[w] = tvalid ? tab[(size_t)w * SP + jc] : -INFINITY;
+#pragma unroll
+        for (int q = 0; q < (W - WR) / 4; ++q) {
+            f32x4 wv4;
+            wv4.x = tvalid ? tab[(size_t)(WR + 4 * q + 0) * SP + jc] : -INFINITY;
+            wv4.y = tvalid ? tab[(size_t)(WR + 4 * q + 1) * SP + jc] : -INFINITY;
+            wv4.z = tvalid ? tab[(size_t)(WR + 4 * q + 2) * SP + jc] : -INFINITY;
+            wv4.w = tvalid ? tab[(size_t)(WR + 4 * q + 3) * SP + jc] : -INFINITY;
+            awl[q * NP + j] = wv4;
+        }
 #pragma unroll
         for (int k = 0; k < NXL; ++k) {
             xcol[k] = k < nx ? a.extras[k] : 0;
@@ -594,7 +607,7 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
 #pragma unroll
     for (int k = 0; k < PF; ++k) er[k] = load_e<ET>(E + (size_t)(1 + k < Tb ? 1 + k : Tb - 1) * S + jld);
 #pragma unroll
-    for (int w = 0; w < W; ++w) asm volatile("" ::"v"(aw[w]));
+    for (int w = 0; w < WR; ++w) asm volatile("" ::"v"(aw[w]));
 #pragma unroll
     for (int k = 0; k < NXL; ++k) asm volatile("" ::"v"(xa[k]));
     asm volatile("" ::"v"(cj));
@@ -629,10 +642,18 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
 #pragma unroll
         for (int w = w0; w + 7 < W && w < w0 + 32; w += 8) {
             const f32x4 da = dw[(w - w0) / 4], db = dw[(w - w0) / 4 + 1];
-            const f32x2 c0_ = f32x2{da.x, da.y} + f32x2{aw[w + 0], aw[w + 1]};
-            const f32x2 c1_ = f32x2{da.z, da.w} + f32x2{aw[w + 2], aw[w + 3]};
-            const f32x2 c2_ = f32x2{db.x, db.y} + f32x2{aw[w + 4], aw[w + 5]};
-            const f32x2 c3_ = f32x2{db.z, db.w} + f32x2{aw[w + 6], aw[w + 7]};
+            f32x4 wa, wb;
+            if (w < WR) {
+                wa = f32x4{aw[w < WR ? w + 0 : 0], aw[w < WR ? w + 1 : 0], aw[w < WR ? w + 2 : 0], aw[w < WR ? w + 3 : 0]};
+                wb = f32x4{aw[w < WR ? w + 4 : 0], aw[w < WR ? w + 5 : 0], aw[w < WR ? w + 6 : 0], aw[w < WR ? w + 7 : 0]};
+            } else {
+                wa = awl[((w - WR) / 4) * NP + j];
+                wb = awl[((w - WR) / 4 + 1) * NP + j];
+            }
+            const f32x2 c0_ = f32x2{da.x, da.y} + f32x2{wa.x, wa.y};
+            const f32x2 c1_ = f32x2{da.z, da.w} + f32x2{wa.z, wa.w};
+            const f32x2 c2_ = f32x2{db.x, db.y} + f32x2{wb.x, wb.y};
+            const f32x2 c3_ = f32x2{db.z, db.w} + f32x2{wb.z, wb.w};
             m0 = fmaxf(fmaxf(m0, c0_.x), c0_.y);
             m1 = fmaxf(fmaxf(m1, c1_.x), c1_.y);
             m2 = fmaxf(fmaxf(m2, c2_.x), c2_.y);
@@ -1475,7 +1496,8 @@ static hipError_t launch_floor_t(const FwdArgs& a, hipStream_t st) {
         }
     }
     constexpr int NWM = (NWT + 3) / 4 * 4;
-    const size_t ldsf = sizeof(float) * (8 * (NP + 16) + 2 * NWM + 64 + NWM) + sizeof(VI) * 16;
+    const size_t ldsf = sizeof(float) * (8 * (NP + 16) + 2 * NWM + 64 + NWM) + sizeof(VI) * 16 +
+                        ((W == 128 && NWT > 8) ? sizeof(f32x4) * 8 * NP : 0);
     if ((W == 32 || W >= 96) && a.n_extras == 1)   // the reference's matrices: band + unvoiced column (compile-time extras count)
         hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, ((W == 32 || W >= 96) ? 1 : -1), PF, ET>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
     else

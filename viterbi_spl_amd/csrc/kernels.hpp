@@ -11,7 +11,7 @@ namespace vit {
 // Banded kernel geometry: NWT target waves (64*NWT >= S), NWT in {2,4,6,8,12}.  Which (W, NWT) combinations are
 // instantiated is bounded by registers: W window entries stay register-resident per thread.
 //   scan form  (banded_forward_kernel: + two scan waves)      W <= 32: NWT <= 12;  W == 64: NWT <= 6
-//   floor form (banded_floor_forward_kernel, plan.floor_ok)   W <= 96: NWT <= 12;  W == 128: NWT <= 8
+//   floor form (banded_floor_forward_kernel, plan.floor_ok)   W <= 128: NWT <= 12 (W = 128 with twelve waves keeps 32 weights in LDS)
 constexpr int banded_waves_for(int S) {
     const int need = (S + 63) / 64;
     const int opts[5] = {2, 4, 6, 8, 12};
@@ -20,7 +20,7 @@ constexpr int banded_waves_for(int S) {
     return 0;
 }
 constexpr bool scan_form_instantiated(int W, int nwt) { return nwt > 0 && ((W <= 32 && nwt <= 12) || (W == 64 && nwt <= 6)); }
-constexpr bool floor_form_instantiated(int W, int nwt) { return nwt > 0 && ((W <= 96 && nwt <= 12) || (W == 128 && nwt <= 8)); }
+constexpr bool floor_form_instantiated(int W, int nwt) { return nwt > 0 && W <= 128 && nwt <= 12; }
 // target waves of the scan form for (S, W), or 0 when it is not instantiated
 constexpr int banded_target_waves(int S, int W) {
     const int nwt = banded_waves_for(S);
