@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--emissions", default="peaks", choices=["peaks", "dense"])
     ap.add_argument("--transition", default="tonet", choices=["tonet", "dense"])
     ap.add_argument("--f16", action="store_true", help="store emissions as float16")
+    ap.add_argument("--dmax", type=int, default=14, help="band half-width of the tonet-recipe transition (tonet 14, jdc 40, imm 56)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--serial", action="store_true", help="no overlap between consecutive steps (one stream)")
@@ -64,7 +65,7 @@ def parse():
 def make_params(args):
     S = args.states
     if args.transition == "tonet":
-        return synth.log_params(synth.tonet_transition(S - 1, 14), synth.floored_prior(S))
+        return synth.log_params(synth.tonet_transition(S - 1, args.dmax), synth.floored_prior(S))
     return synth.dense_random_log_transition(S, seed=3), synth.dense_random_log_transition(S, seed=4)[0].copy()
 
 
@@ -233,7 +234,8 @@ def main():
                                    f"(BASELINE configs[2]; configs[3] at 8 GPUs), forward + back-trace"
                                    + (" + RCCL gather of paths" if use_dist else ""),
                        "songs_per_gpu": B, "frames": T, "states": S, "emissions": args.emissions,
-                       "transition": args.transition, "forward_kernel": algo, "plan": dec.info},
+                       "transition": args.transition, "band_half_width": args.dmax if args.transition == "tonet" else None,
+                       "forward_kernel": algo, "plan": dec.info},
             "roofline": {"bound": "hbm", "kernel": fwd_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": fwd_bytes, "avg_launch_ms": fwd_ms,
