@@ -122,10 +122,12 @@ def main():
     dt = torch.float16 if args.f16 else torch.float32
     E = gen(B, T, S, seed=1234, device=dev, dtype=dt, first_song=rank * B)
     n_total = B * world
-    NSLOT = 2
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"     # the latter: rehearse the gather path on one GPU
+    NSLOT = 2 if use_dist else 1                   # batches in flight (the gather of step i overlaps step i+1)
+    for k in range(NSLOT):
+        dec._workspace(B, T, k)                     # allocate before anything is timed
     states_k = [torch.empty((B, T), dtype=torch.int32, device=dev) for _ in range(NSLOT)]
     loglik_k = [torch.empty((B,), dtype=torch.float32, device=dev) for _ in range(NSLOT)]
-    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"     # the latter: rehearse the gather path on one GPU
     if use_dist and not dist.is_initialized():
         dist.init_process_group("nccl", device_id=dev)
     if use_dist and rank == 0:
