@@ -717,8 +717,7 @@ __global__ void __launch_bounds__(NPW * 64) banded_floor_pair_forward_kernel(Fwd
     constexpr int NP = NPW * 128;                 // padded state count
     constexpr int DC = NP + 16;                   // copy stride (see banded_forward_kernel)
     constexpr int BUF = 4 * DC;                   // floats per delta buffer
-    constexpr int NWM = 4;                        // wave maxima per buffer (NPW <= 4), one float4
-    static_assert(NPW <= 4, "one float4 of wave maxima");
+    constexpr int NWM = (NPW + 3) / 4 * 4;        // wave maxima per buffer, whole float4s (slots >= NPW hold -inf)
     float* dls = reinterpret_cast<float*>(smem);  // [2][4][DC]
     float* wm = dls + 2 * BUF;                    // [2][NWM]
     float* dump = wm + 2 * NWM;                   // [64 + NWM]
@@ -817,7 +816,9 @@ __global__ void __launch_bounds__(NPW * 64) banded_floor_pair_forward_kernel(Fwd
         float xd[NXL > 0 ? NXL : 1];
 #pragma unroll
         for (int k = 0; k < NXL; ++k) xd[k] = dls[4 + sh + RB * BUF + xcol[k]];
-        const f32x4 wq = *reinterpret_cast<const f32x4*>(wm + RB * NWM);
+        f32x4 wq[NWM / 4];
+#pragma unroll
+        for (int q = 0; q < NWM / 4; ++q) wq[q] = reinterpret_cast<const f32x4*>(wm + RB * NWM)[q];
         f32x4 dw[W / 4];
 #pragma unroll
         for (int q = 0; q < W / 4; ++q) dw[q] = win[q];
@@ -835,7 +836,9 @@ __global__ void __launch_bounds__(NPW * 64) banded_floor_pair_forward_kernel(Fwd
             n1 = fmaxf(fmaxf(n1, b1.x), b1.y);
         }
         // M = max of delta_{t-1} over the non-extra sources; slots >= NPW of wq hold -inf
-        const float M = fmaxf(fmaxf(wq.x, wq.y), fmaxf(wq.z, wq.w));
+        float M = fmaxf(fmaxf(wq[0].x, wq[0].y), fmaxf(wq[0].z, wq[0].w));
+#pragma unroll
+        for (int q = 1; q < NWM / 4; ++q) M = fmaxf(fmaxf(fmaxf(M, wq[q].x), wq[q].y), fmaxf(wq[q].z, wq[q].w));
         const f32x2 fl = f32x2{M, M} + cj;
         m0 = fmaxf(m0, fl.x);
         m1 = fmaxf(m1, fl.y);
@@ -1483,11 +1486,12 @@ static hipError_t launch_floor_t(const FwdArgs& a, hipStream_t st) {
     // Up to two songs per CU the one-target-per-lane kernel is (slightly) faster; beyond that the two-targets-per-lane
     // kernel wins because it moves half the window bytes through LDS (B = 512: 14.5 vs 15.5 ms).
     // VIT_DEBUG_FLAGS 512 / 1024 force one or the other.
-    if constexpr (W <= 32 && NWT <= 8) {
+    if constexpr (W <= 32 && NWT <= 8) {   // (at twelve waves, S = 722, the one-target kernel measured faster at every batch size)
         const bool pair = a.pair_ok && ((a.B > 256 && !(a.debug & 512)) || (a.debug & 1024));
         if (pair) {
             constexpr int NPW = (NWT + 1) / 2;
-            const size_t ldsp = sizeof(float) * (8 * (NPW * 128 + 16) + 2 * 4 + 64 + 4) + sizeof(VI) * 16;
+            constexpr int NWMP = (NPW + 3) / 4 * 4;
+            const size_t ldsp = sizeof(float) * (8 * (NPW * 128 + 16) + 2 * NWMP + 64 + NWMP) + sizeof(VI) * 16;
             if (W == 32 && a.n_extras == 1)
                 hipLaunchKernelGGL((banded_floor_pair_forward_kernel<W, NPW, (W == 32 ? 1 : -1), PF, ET>), dim3((int)a.B), dim3(NPW * 64), ldsp, st, a);
             else
