@@ -192,7 +192,7 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
     if (algo == VIT_ALGO_BANDED) {
         e = vit::launch_banded(a, emis_dtype == VIT_F16, (hipStream_t)stream);
     } else {
-        int ns = B >= 1024 ? 4 : (B >= 512 ? 2 : 1);
+        int ns = B >= 512 ? 2 : 1;   // songs per workgroup share the streamed matrix (measured at S = 361, B = 1024: 1 -> 57, 2 -> 64, 4 -> 48 Mframes/s)
         if (const char* e = std::getenv("VIT_DENSE_NS")) ns = std::atoi(e);   // timing experiments only
         e = vit::launch_dense(a, ns, emis_dtype == VIT_F16, (hipStream_t)stream);
     }
