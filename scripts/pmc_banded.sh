@@ -7,10 +7,11 @@ rm -rf $OUT && mkdir -p $OUT
 run() { rocprofv3 --pmc "$@" --output-format csv -d $OUT/$1 -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>> $OUT/err.log; }
 run SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA
 run SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
-python3 - <<'PY'
+PMC_OUT=$OUT python3 - <<'PY'
 import csv, glob, collections
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob("gpurun_out/pmc_*/**/*counter_collection.csv", recursive=True):
+import os
+for f in glob.glob(os.environ.get("PMC_OUT", "gpurun_out/pmc_r01") + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "vit::" in k:
