@@ -81,6 +81,9 @@ def main():
     params["tonet361"] = synth.log_params(A_to, pi_to)
     logA_du = np.require(np.log(A_du).astype(np.float32).T, np.float32, ["C"])
     params["durrieu722"] = (logA_du, np.log(np.full(722, 1.0 / 722)).astype(np.float32))
+    # the 722-state grids with the band half-widths of jdc (40) and imm's post-processing matrix (56): W = 96 / 128 windows
+    params["jdc722"] = synth.log_params(synth.tonet_transition(721, 40), synth.floored_prior(722))
+    params["imm722w"] = synth.log_params(synth.tonet_transition(721, 56), synth.floored_prior(722))
     params["dense361"] = (synth.dense_random_log_transition(361, seed=3),
                           synth.dense_random_log_transition(361, seed=4)[0].copy())
     params["dense97"] = (synth.dense_random_log_transition(97, seed=5),
@@ -107,6 +110,10 @@ def main():
     add("durrieu722", "dense", 300, 41)
     add("durrieu722", "peaks", 300, 42)
     add("durrieu722", "dense", 200, 43, f16=True)
+    add("jdc722", "peaks", 300, 51)
+    add("jdc722", "ties", 200, 52, f16=True)
+    add("imm722w", "peaks", 200, 53)
+    add("imm722w", "dense", 150, 54, f16=True)
     add("tonet361", "peaks", 30000, 1)
     add("tonet361", "dense", 30000, 2)
     add("msnet321", "peaks", 30000, 3)
