@@ -1032,7 +1032,7 @@ __global__ void __launch_bounds__(512) banded_backtrace_kernel(BtArgs a) {
                 float mf = 0.f, cj = 0.f;
 #pragma unroll
                 for (int k = 0; k < KC; ++k)
-                    if (k == kb) {
+                    if (KC == 1 || k == kb) {
                         mf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), lb));
                         cj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(av[k]), lb));
                     }
