@@ -136,6 +136,7 @@ def main():
     else:
         out_k = [(None, None)] * NSLOT
     pending = [None] * NSLOT
+    gather_mode = ["async"]
 
     def step(i, ev=None, overlap_gather=True):
         """forward(i), back-trace(i) on the current stream; the gather of the paths on the communicator's stream."""
@@ -153,8 +154,16 @@ def main():
         if ev is not None:
             ev[2].record()
         if use_dist:
-            pending[k] = sharded.gather_paths_async(states_k[k], loglik_k[k], out_k[k][0], out_k[k][1], dst=0)
-            if not overlap_gather:
+            if gather_mode[0] == "async":
+                try:
+                    pending[k] = sharded.gather_paths_async(states_k[k], loglik_k[k], out_k[k][0], out_k[k][1], dst=0)
+                except Exception as exc:           # defensive: fall back to the plain blocking gather
+                    if rank == 0:
+                        print(f"bench: non-blocking gather unavailable ({exc!r}); using the blocking gather", file=sys.stderr)
+                    gather_mode[0] = "blocking"
+            if gather_mode[0] == "blocking":
+                sharded.gather_paths(states_k[k], loglik_k[k], n_total, dst=0)
+            elif not overlap_gather:
                 for w in pending[k]:
                     w.wait()
                 pending[k] = None
@@ -246,7 +255,7 @@ def main():
                                  "implementation stores the float32 delta row instead (lazy back-pointers, DESIGN.md), "
                                  "and the recursion is fp32-VALU / latency bound, not HBM bound"},
             "kernels_ms": {"forward": fwd_ms, "backtrace": bt_ms},
-            "gather": (None if not use_dist else ("blocking (--serial)" if args.serial else
+            "gather": (None if not use_dist else ("blocking" if (args.serial or gather_mode[0] == "blocking") else
                        "non-blocking on the communicator's stream, completes under the next step's forward pass; two path-buffer slots")),
             "backtrace": {"algorithmic_bytes_per_launch": bt_bytes, "traffic": bt_traffic,
                           "implementation_bytes_per_frame": SD * 4,
