@@ -137,19 +137,27 @@ __device__ __forceinline__ void terminal_argmax(float dj, int j, bool valid, VI*
 // vectors are read from LDS as wave-uniform (broadcast) 16-byte reads.  Value-only: two packed
 // adds and two max3 per four sources.
 // ---------------------------------------------------------------------------------------
-template <int NS, typename ET>
-__global__ void __launch_bounds__(dense_max_threads(NS)) dense_forward_kernel(FwdArgs a) {
+template <int NS, typename ET, int KT = 1>
+__global__ void __launch_bounds__(KT == 2 ? 1024 : dense_max_threads(NS)) dense_forward_kernel(FwdArgs a) {
+    // KT = 2: two threads per target, each walks half of the sources (twice the waves = twice the transition loads in
+    // flight: the kernel is bound by the latency of streaming the matrix through L2, not by arithmetic); the halves meet
+    // through LDS once per frame.
     extern __shared__ __align__(16) unsigned char smem[];
     const int S = a.S, SP = a.SP, S4 = a.S4, T = a.T, SD = a.SD;
     float* dl = reinterpret_cast<float*>(smem);  // [2][NS][SD]
-    VI* tot = reinterpret_cast<VI*>(dl + 2 * NS * SD);
+    float* part = dl + 2 * NS * SD;              // [NS][SP] partial maxima of the upper half (KT == 2)
+    VI* tot = reinterpret_cast<VI*>(part + (KT == 2 ? NS * SP : 0) + ((2 * NS * SD + (KT == 2 ? NS * SP : 0)) & 1));
 
-    const int j = threadIdx.x;
+    const int half = KT == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >= (unsigned)SP)) : 0;   // SP is a multiple of 64
+    const int j = threadIdx.x - half * SP;
+    const bool lead = half == 0;                 // the thread that owns target j
     const int nw = blockDim.x >> 6;
     const int song0 = blockIdx.x * NS;
     const float4* __restrict__ A4 = reinterpret_cast<const float4*>(a.image + a.off_A4);
     const float* __restrict__ log_pi = reinterpret_cast<const float*>(a.image + a.off_logpi);
     const ET* __restrict__ E = reinterpret_cast<const ET*>(a.logE);
+    const int qmid = KT == 2 ? (S4 + 1) / 2 : S4;
+    const int q_lo = half ? qmid : 0, q_hi = half ? S4 : qmid;
 
     int Tb[NS];
     bool live[NS];
@@ -166,12 +174,12 @@ __global__ void __launch_bounds__(dense_max_threads(NS)) dense_forward_kernel(Fw
     for (int s = 0; s < NS; ++s) {
         const size_t base = (size_t)(song0 + s) * T * S;
         float d = -INFINITY;
-        if (live[s] && j < S) {
+        if (lead && live[s] && j < S) {
             d = log_pi[j] + load_e<ET>(E + base + j);
             a.hist[(size_t)(song0 + s) * T * SD + j] = d;
         }
-        if (j < SD) { dl[(0 * NS + s) * SD + j] = d; dl[(1 * NS + s) * SD + j] = -INFINITY; }
-        enext[s] = (live[s] && j < S && Tb[s] > 1) ? load_e<ET>(E + base + S + j) : 0.f;
+        if (lead && j < SD) { dl[(0 * NS + s) * SD + j] = d; dl[(1 * NS + s) * SD + j] = -INFINITY; }
+        enext[s] = (lead && live[s] && j < S && Tb[s] > 1) ? load_e<ET>(E + base + S + j) : 0.f;
     }
     __syncthreads();
 
@@ -181,7 +189,7 @@ __global__ void __launch_bounds__(dense_max_threads(NS)) dense_forward_kernel(Fw
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             ecur[s] = enext[s];
-            if (live[s] && j < S && t + 1 < Tb[s])
+            if (lead && live[s] && j < S && t + 1 < Tb[s])
                 enext[s] = load_e<ET>(E + ((size_t)(song0 + s) * T + t + 1) * S + j);
         }
         float b0[NS], b1[NS];
@@ -189,7 +197,7 @@ __global__ void __launch_bounds__(dense_max_threads(NS)) dense_forward_kernel(Fw
         for (int s = 0; s < NS; ++s) { b0[s] = -INFINITY; b1[s] = -INFINITY; }
         const float* dcur = dl + cur * NS * SD;
 #pragma unroll 8
-        for (int q = 0; q < S4; ++q) {
+        for (int q = q_lo; q < q_hi; ++q) {
             const float4 av = A4[(size_t)q * SP + j];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -198,10 +206,21 @@ __global__ void __launch_bounds__(dense_max_threads(NS)) dense_forward_kernel(Fw
                 b1[s] = fmaxf(fmaxf(b1[s], dv.z + av.z), dv.w + av.w);
             }
         }
+        if (KT == 2) {
+            if (!lead) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) part[s * SP + j] = fmaxf(b0[s], b1[s]);
+            }
+            __syncthreads();
+            if (lead) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) b0[s] = fmaxf(b0[s], part[s * SP + j]);
+            }
+        }
         float* dnxt = dl + (cur ^ 1) * NS * SD;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            if (j < S) {
+            if (lead && j < S) {
                 if (live[s] && t < Tb[s]) {
                     const float dn = fmaxf(b0[s], b1[s]) + ecur[s];
                     dnxt[s * SD + j] = dn;
@@ -218,8 +237,9 @@ __global__ void __launch_bounds__(dense_max_threads(NS)) dense_forward_kernel(Fw
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         if (live[s]) {
-            const float dj = j < S ? dl[(cur * NS + s) * SD + j] : -INFINITY;
-            terminal_argmax(dj, j, j < S, tot, nw, a.last_state, a.loglik, song0 + s);
+            const bool valid = lead && j < S;
+            const float dj = valid ? dl[(cur * NS + s) * SD + j] : -INFINITY;
+            terminal_argmax(dj, j, valid, tot, nw, a.last_state, a.loglik, song0 + s);
         }
         __syncthreads();
     }
@@ -1456,16 +1476,19 @@ __global__ void scan_selftest_kernel(const float* __restrict__ vals, int mode, f
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
-template <int NS, typename ET>
+template <int NS, typename ET, int KT = 1>
 static hipError_t launch_dense_t(const FwdArgs& a, hipStream_t st) {
-    const size_t lds = sizeof(float) * 2 * NS * a.SD + sizeof(VI) * 16;
+    const size_t lds = sizeof(float) * (2 * NS * a.SD + (KT == 2 ? NS * a.SP : 0) + 1) + sizeof(VI) * 16;
     const int grid = (int)((a.B + NS - 1) / NS);
-    hipLaunchKernelGGL((dense_forward_kernel<NS, ET>), dim3(grid), dim3(a.SP), lds, st, a);
+    hipLaunchKernelGGL((dense_forward_kernel<NS, ET, KT>), dim3(grid), dim3(KT * a.SP), lds, st, a);
     return hipGetLastError();
 }
 
 hipError_t launch_dense(const FwdArgs& a, int ns, bool f16, hipStream_t st) {
     while (ns > 1 && a.SP > dense_max_threads(ns)) ns >>= 1;
+    // one song per workgroup: two threads per target when the workgroup still fits (S <= 512)
+    if (ns == 1 && 2 * a.SP <= 1024 && !(a.debug & 16384))
+        return f16 ? launch_dense_t<1, __half, 2>(a, st) : launch_dense_t<1, float, 2>(a, st);
     if (f16) {
         if (ns >= 8) return launch_dense_t<8, __half>(a, st);
         if (ns >= 4) return launch_dense_t<4, __half>(a, st);
