@@ -73,7 +73,7 @@ typedef struct vit_plan_info {
     int32_t n_extras;       /* extra exception columns shared by most rows */
     int32_t max_window;     /* widest per-row exception window */
     int32_t group_window;   /* window width the banded kernel evaluates per target */
-    int32_t reserved[3];    /* [0] dense rows, [1] one-maximum ("floor") form proven, [2] bit 0: window start affine in the target, bit 1: pair windows proven */
+    int32_t reserved[3];    /* [0] dense rows, [1] one-maximum ("floor") form proven, [2] bit 0: window start affine in the target, bit 1: pair windows proven, bit 2: step structure (dense matrix, piecewise-constant columns) */
     float consts[4];
     int32_t extras[4];
 } vit_plan_info;

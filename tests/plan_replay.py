@@ -47,6 +47,9 @@ class HostPlan:
         self.S4 = int(info[15]) & 0xFFFF
         self.pair_ok = bool(int(info[15]) & 0x10000)
         self.floor_ok = bool(int(info[15]) & 0x20000)
+        self.step_ok = bool(int(info[15]) & 0x40000)
+        self.step_kb = (int(info[15]) >> 20) & 0xF
+        self.step_bw = (int(info[15]) >> 24) & 0x7F
         self.c0 = np.float32(c0[0])
         SP, S4 = self.SP, self.S4
 

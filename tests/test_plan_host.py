@@ -157,3 +157,40 @@ def test_wide_bands_of_the_high_resolution_grids(n_bins, d_max, W):
     st, ll, delta = replay_banded(plan, E, floor=True)
     ref, rl, rdelta = vo.decode_c(logA_T, log_pi, E, return_delta=True)
     assert np.array_equal(st, ref) and delta.tobytes() == rdelta.tobytes()
+
+
+def test_step_structure_of_the_durrieu_matrix(golden):
+    """imm's own decoder uses a dense matrix whose columns are piecewise constant in 20-bin distance bands; the plan must
+    prove that from the bits (and refuse as soon as one entry breaks it), and the max of band-window maxima plus ONE
+    far maximum must reproduce the dense recursion bit for bit."""
+    p = golden["params"]
+    A, pi = p["durrieu722_logA_T"], p["durrieu722_log_pi"]
+    plan = HostPlan(A, pi)
+    assert not plan.ok and plan.step_ok and plan.step_bw == 20 and plan.step_kb == 9
+    B = A.copy()
+    B[300, 310] = np.nextafter(B[300, 310], np.float32(0))          # one entry one ulp off: not a step matrix any more
+    assert not HostPlan(B, pi).step_ok
+    assert not HostPlan(p["dense361_logA_T"], p["dense361_log_pi"]).step_ok
+    # host replay of step_forward_kernel's arithmetic
+    S, n, BW, KB = 722, 721, 20, 9
+    E = synth.emissions_dense(1, 40, S, seed=12)[0].numpy()
+    ref, rl, rdelta = vo.decode_c(A, pi, E, return_delta=True)
+    C = np.stack([A[np.minimum(np.arange(n) + k * BW, n - 1), np.arange(n)] if k * BW < n else None for k in range(KB + 1)])
+    for i in range(n):                                               # band value of source i at distance k*BW (either side)
+        for k in range(KB + 1):
+            j = i + k * BW if i + k * BW < n else i - k * BW
+            C[k, i] = A[j, i]
+    delta = (pi + E[0]).astype(np.float32)
+    ninf = np.float32(-np.inf)
+    for t in range(1, E.shape[0]):
+        V = (delta[None, :n] + C).astype(np.float32)                 # [KB+1, n]
+        M = max(np.max(V[KB]), np.float32(delta[n] + A[0, n]))
+        m = np.full(S, ninf, np.float32)
+        for j in range(n):
+            best = M
+            for i in range(max(0, j - KB * BW + 1), min(n, j + KB * BW)):
+                best = max(best, V[abs(i - j) // BW, i])
+            m[j] = best
+        m[n] = np.max((delta + A[n]).astype(np.float32))
+        delta = (m + E[t]).astype(np.float32)
+    assert delta.tobytes() == rdelta.tobytes()

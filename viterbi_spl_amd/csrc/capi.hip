@@ -82,6 +82,7 @@ int vit_plan_create(const float* logA_T, const float* log_pi, int64_t S, vit_pla
     try {
         p->S = (int)S;
         p->bp = vit::analyze_banded(logA_T, (int)S);
+        if (!p->bp.ok) vit::analyze_step(logA_T, (int)S, p->bp);
         p->L = vit::make_layout((int)S, p->bp);
         p->host_image.resize(p->L.bytes);
         vit::fill_image(logA_T, log_pi, p->bp, p->L, p->host_image.data());
@@ -106,7 +107,8 @@ int vit_plan_query(const vit_plan* plan, vit_plan_info* info) {
     info->group_window = plan->bp.W;
     info->reserved[0] = plan->bp.n_dense;
     info->reserved[1] = plan->bp.ok && plan->bp.floor_ok ? 1 : 0;
-    info->reserved[2] = (plan->bp.ok && plan->bp.lo_affine ? 1 : 0) | (plan->bp.ok && plan->bp.pair_ok ? 2 : 0);
+    info->reserved[2] = (plan->bp.ok && plan->bp.lo_affine ? 1 : 0) | (plan->bp.ok && plan->bp.pair_ok ? 2 : 0) |
+                        (plan->bp.step_ok && vit::step_kernel_instantiated(plan->S, plan->bp.step_bw, plan->bp.step_kb) ? 4 : 0);
     info->consts[0] = plan->bp.c0;
     for (int k = 0; k < vit::kMaxExtras; ++k) info->extras[k] = k < plan->bp.n_extras ? plan->bp.extras[k] : -1;
     return VIT_OK;
@@ -147,6 +149,7 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
     if (!logE) return VIT_EINVAL;
     if (emis_dtype != VIT_F32 && emis_dtype != VIT_F16) return VIT_EINVAL;
     if (B == 0) return VIT_OK;
+    const int requested = algo;
     algo = resolve_algo(plan, algo);
     if (algo < 0) return algo;
 
@@ -184,6 +187,12 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
     a.off_tabP = plan->L.off_tabP;
     a.pair_ok = plan->bp.ok && plan->bp.pair_ok ? 1 : 0;
     a.floor_ok = plan->bp.ok && plan->bp.floor_ok ? 1 : 0;
+    a.step_ok = plan->bp.step_ok ? 1 : 0;
+    a.step_bw = plan->bp.step_bw;
+    a.step_kb = plan->bp.step_kb;
+    a.step_cn = plan->bp.step_cn;
+    a.off_stepC = plan->L.off_stepC;
+    a.off_Arow = plan->L.off_Arow;
     a.win_shift = (plan->bp.ok && plan->bp.lo_affine) ? (plan->bp.lo_off & 3) : 0;
     a.win_shift2 = (plan->bp.ok && plan->bp.pair_ok && plan->bp.lo2_affine) ? (plan->bp.lo2_off & 3) : 0;
     if (const char* e = std::getenv("VIT_WIN_SHIFT")) a.win_shift = a.win_shift2 = std::atoi(e) & 3;   // timing experiments only
@@ -191,6 +200,10 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
     hipError_t e;
     if (algo == VIT_ALGO_BANDED) {
         e = vit::launch_banded(a, emis_dtype == VIT_F16, (hipStream_t)stream);
+    } else if (requested == VIT_ALGO_AUTO && a.step_ok && vit::step_kernel_instantiated(a.S, a.step_bw, a.step_kb) &&
+               !(a.debug & 16384)) {
+        // dense matrix with step structure (Durrieu): VIT_ALGO_DENSE still means the plain dense kernel
+        e = vit::launch_step(a, emis_dtype == VIT_F16, (hipStream_t)stream);
     } else {
         int ns = B >= 512 ? 2 : 1;   // songs per workgroup share the streamed matrix (measured at S = 361, B = 1024: 1 -> 57, 2 -> 64, 4 -> 48 Mframes/s)
         if (const char* e = std::getenv("VIT_DENSE_NS")) ns = std::atoi(e);   // timing experiments only

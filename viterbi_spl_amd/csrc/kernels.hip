@@ -246,6 +246,147 @@ __global__ void __launch_bounds__(KT == 2 ? 1024 : dense_max_threads(NS)) dense_
 }
 
 // ---------------------------------------------------------------------------------------
+// Step-structured forward kernel (plan.step_ok: the Durrieu matrix of imm's own decoder, S = 722).
+//
+// For voiced source i and voiced target j, logA_T[j][i] = C[min(|i-j| / BW, KB)][i]: column i is piecewise constant in
+// distance bands of BW bins and constant from distance KB*BW on.  So fl(delta_i + logA_T[j][i]) takes only KB+1 values
+// per source: every thread publishes V_k[i] = fl(delta_i + C[k][i]) for its own state, and target j takes the max of
+// the band windows V_k[j + k*BW .. j + k*BW + BW) and V_k(j - k*BW - BW .. j - k*BW] -- exactly the sums the dense
+// recursion forms.  The far sources (distance >= KB*BW) reduce to ONE number, M = max_i V_KB[i]: if its arg-max is far
+// from j it IS the far term, if it is near, its near-band value is >= M (no near band of a column is below the far
+// value: checked by the plan; rounding is monotone) and every far term is <= M.  The unvoiced source contributes one
+// value to every voiced target and joins M; the unvoiced target's row is arbitrary and gets a wave of its own.
+// 2*KB*BW window reads per target instead of S global transition entries: the matrix is never streamed.
+// One workgroup per song, NWV waves of voiced states + one wave for the unvoiced state, one barrier per frame
+// (V is double-buffered).  Value-only like every forward kernel here; the generic back-trace follows.
+// ---------------------------------------------------------------------------------------
+template <int BW, int KB, int NWV, int PF, typename ET>
+__global__ void __launch_bounds__((NWV + 1) * 64) step_forward_kernel(FwdArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int NPV = NWV * 64;                 // padded voiced states
+    constexpr int PAD = KB * BW + BW;             // -inf margin on both sides of every V_k
+    constexpr int VLEN = NPV + 2 * PAD;
+    constexpr int DLEN = NPV + 64;
+    constexpr int NWM = (NWV + 1 + 3) / 4 * 4;    // wave maxima of V_KB + the unvoiced source's candidate
+    float* V = reinterpret_cast<float*>(smem);    // [2][KB][VLEN]
+    float* dl = V + 2 * KB * VLEN;                // [2][DLEN]  delta itself (for the unvoiced target's row)
+    float* wm = dl + 2 * DLEN;                    // [2][NWM]
+    VI* tot = reinterpret_cast<VI*>(wm + 2 * NWM);
+    const int S = a.S, SP = a.SP, T = a.T, SD = a.SD;
+    const int n = S - 1;                          // voiced states 0 .. n-1, unvoiced state n
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int song = blockIdx.x;
+    const int Tb = song_length(a.lengths, song, T);
+    const ET* __restrict__ E = reinterpret_cast<const ET*>(a.logE) + (size_t)song * T * S;
+    float* __restrict__ hist = a.hist + (size_t)song * T * SD;
+    const float* __restrict__ lpi = reinterpret_cast<const float*>(a.image + a.off_logpi);
+
+    for (int k = tid; k < 2 * KB * VLEN + 2 * DLEN + 2 * NWM; k += (NWV + 1) * 64) V[k] = -INFINITY;
+    __syncthreads();
+
+    const bool voiced_wave = wv < NWV;
+    const int j = tid;                                                    // voiced waves: own state
+    const bool valid = voiced_wave && j < n;
+    const int jld = valid ? j : n;                                        // emission column loaded (the unvoiced wave: column n)
+    float c[KB + 1];                                                      // band values of source j
+    {
+        const float* __restrict__ sc = reinterpret_cast<const float*>(a.image + a.off_stepC);
+#pragma unroll
+        for (int k = 0; k <= KB; ++k) c[k] = valid ? sc[(size_t)k * SP + j] : -INFINITY;
+    }
+    constexpr int NQ = NWV + 1;                                           // sources per lane of the unvoiced target's wave
+    float rown[NQ];
+    {
+        const float* __restrict__ ar = reinterpret_cast<const float*>(a.image + a.off_Arow) + (size_t)n * SP;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) rown[q] = (!voiced_wave && lane + 64 * q < SP) ? ar[lane + 64 * q] : -INFINITY;   // -inf beyond S
+    }
+    const float cn = a.step_cn;
+
+    float dn;                                                             // delta of the own state (unvoiced wave: of state n, every lane)
+    {
+        const float e0 = load_e<ET>(E + jld);
+        dn = (valid || !voiced_wave) ? lpi[jld] + e0 : -INFINITY;
+        if (valid || (!voiced_wave && lane == 0)) hist[jld] = dn;
+    }
+    float er[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) er[k] = load_e<ET>(E + (size_t)(1 + k < Tb ? 1 + k : Tb - 1) * S + jld);
+
+    auto frame = [&](const int t, float& e_slot, const int b) {
+        // ---- publish delta_{t-1} into buffer b
+        if (voiced_wave) {
+            float* vb = V + b * KB * VLEN + PAD + j;
+#pragma unroll
+            for (int k = 0; k < KB; ++k) vb[k * VLEN] = dn + c[k];
+            if (valid) dl[b * DLEN + j] = dn;                              // (entry n belongs to the unvoiced wave)
+            const float inc = wave_scan_max(dn + c[KB]);
+            if (lane == 63) wm[b * NWM + wv] = inc;
+        } else if (lane == 0) {
+            dl[b * DLEN + n] = dn;
+            wm[b * NWM + NWV] = dn + cn;
+        }
+        __syncthreads();
+        // ---- consume
+        float m;
+        if (voiced_wave) {
+            const float* rb = V + b * KB * VLEN + PAD + j;
+            float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+            // band 0: distances 0 .. BW-1 on both sides (2*BW - 1 sources; one padded read keeps the pairs even)
+#pragma unroll
+            for (int r = -(BW - 1); r + 3 < BW + 1; r += 4) {
+                m0 = fmaxf(fmaxf(m0, rb[r]), rb[r + 1]);
+                m1 = fmaxf(fmaxf(m1, rb[r + 2]), r + 3 <= BW - 1 ? rb[r + 3] : -INFINITY);
+            }
+#pragma unroll
+            for (int k = 1; k < KB; ++k) {
+                const float* rk = rb + k * VLEN;
+#pragma unroll
+                for (int r = 0; r + 3 < BW; r += 4) {
+                    m2 = fmaxf(fmaxf(m2, rk[k * BW + r]), rk[k * BW + r + 1]);
+                    m3 = fmaxf(fmaxf(m3, rk[k * BW + r + 2]), rk[k * BW + r + 3]);
+                    m0 = fmaxf(fmaxf(m0, rk[-k * BW - r]), rk[-k * BW - r - 1]);
+                    m1 = fmaxf(fmaxf(m1, rk[-k * BW - r - 2]), rk[-k * BW - r - 3]);
+                }
+            }
+            // the far sources and the unvoiced source: one maximum
+            float M = -INFINITY;
+#pragma unroll
+            for (int q = 0; q < NWM / 4; ++q) {
+                const f32x4 w = reinterpret_cast<const f32x4*>(wm + b * NWM)[q];
+                M = fmaxf(fmaxf(fmaxf(M, w.x), w.y), fmaxf(w.z, w.w));
+            }
+            m = fmaxf(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)), M);
+        } else {
+            // the unvoiced target: every source through its own (arbitrary) row
+            float mm = -INFINITY;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) mm = fmaxf(mm, dl[b * DLEN + (lane + 64 * q < DLEN ? lane + 64 * q : DLEN - 1)] + rown[q]);
+            m = wave_max_all(mm);
+        }
+        dn = (valid || !voiced_wave) ? m + e_slot : -INFINITY;
+        const int tn = t + PF < Tb ? t + PF : Tb - 1;
+        if (valid || (!voiced_wave && lane == 0)) hist[(size_t)t * SD + jld] = dn;
+        e_slot = load_e<ET>(E + (size_t)tn * S + jld);
+    };
+    static_assert(BW % 4 == 0 && PF % 2 == 0, "band width in whole quads, even prefetch depth");
+    int t = 1;
+    for (; t + PF - 1 < Tb; t += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) frame(t + k, er[k], (k + 1) & 1);
+    }
+#pragma unroll
+    for (int k = 0; k < PF - 1; ++k)
+        if (t + k < Tb) frame(t + k, er[k], (k + 1) & 1);
+
+    __syncthreads();
+    terminal_argmax(dn, voiced_wave ? j : n, valid || (!voiced_wave && lane == 0), tot, NWV + 1, a.last_state, a.loglik, song);
+}
+
+// ---------------------------------------------------------------------------------------
 // Banded forward kernel: one song per workgroup, value-only.
 //
 // For a banded target j (window [lo_j, lo_j+W), row constant c_j, extra columns X):
@@ -1481,6 +1622,18 @@ static hipError_t launch_dense_t(const FwdArgs& a, hipStream_t st) {
     const size_t lds = sizeof(float) * (2 * NS * a.SD + (KT == 2 ? NS * a.SP : 0) + 1) + sizeof(VI) * 16;
     const int grid = (int)((a.B + NS - 1) / NS);
     hipLaunchKernelGGL((dense_forward_kernel<NS, ET, KT>), dim3(grid), dim3(KT * a.SP), lds, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_step(const FwdArgs& a, bool f16, hipStream_t st) {
+    constexpr int BW = 20, KB = 9, NWV = 12, PF = 2;
+    if (!step_kernel_instantiated(a.S, a.step_bw, a.step_kb)) return hipErrorInvalidConfiguration;
+    constexpr int VLEN = NWV * 64 + 2 * (KB * BW + BW);
+    const size_t lds = sizeof(float) * (2 * KB * VLEN + 2 * (NWV * 64 + 64) + 2 * 16) + sizeof(VI) * 16;
+    if (f16)
+        hipLaunchKernelGGL((step_forward_kernel<BW, KB, NWV, PF, __half>), dim3((int)a.B), dim3((NWV + 1) * 64), lds, st, a);
+    else
+        hipLaunchKernelGGL((step_forward_kernel<BW, KB, NWV, PF, float>), dim3((int)a.B), dim3((NWV + 1) * 64), lds, st, a);
     return hipGetLastError();
 }
 

@@ -26,6 +26,8 @@ constexpr int banded_target_waves(int S, int W) {
     const int nwt = banded_waves_for(S);
     return scan_form_instantiated(W, nwt) ? nwt : 0;
 }
+// step-structured kernel (plan.step_ok): instantiated for the Durrieu geometry -- 20-bin bands, 9 near bands, 705..768 voiced states
+constexpr bool step_kernel_instantiated(int S, int bw, int kb) { return bw == 20 && kb == 9 && S - 1 > 704 && S - 1 <= 768; }
 // the dense kernel keeps NS running (best, arg) pairs per thread
 constexpr int dense_max_threads(int NS) { return NS <= 2 ? 1024 : 512; }
 
@@ -47,6 +49,9 @@ struct FwdArgs {
     size_t off_logpi, off_A4, off_lo, off_kind, off_tabA, off_extraA, off_denseA, off_rowc, off_lo2, off_tabP;
     int pair_ok;            // the plan proved pair windows: use the two-targets-per-lane kernel
     int floor_ok;           // the plan proved the one-maximum form (banded_floor_forward_kernel)
+    int step_ok, step_bw, step_kb;   // step structure (step_forward_kernel)
+    float step_cn;          // logA_T[j][S-1] for every voiced target j
+    size_t off_stepC, off_Arow;
     int win_shift2;         // the same for the pair windows of banded_floor_pair_forward_kernel
     int win_shift;          // 0..3: delta is stored shifted by this many floats in LDS so that the window starts of a
                             // 16-lane group are 16-byte aligned in the SAME copy order (bank-conflict-free b128 reads)
@@ -74,6 +79,7 @@ struct BtArgs {
 };
 
 hipError_t launch_dense(const FwdArgs& a, int songs_per_group, bool f16, hipStream_t st);
+hipError_t launch_step(const FwdArgs& a, bool f16, hipStream_t st);
 hipError_t launch_banded(const FwdArgs& a, bool f16, hipStream_t st);
 hipError_t launch_backtrace(BtArgs a, hipStream_t st);
 hipError_t launch_voicing_map(const int32_t* states, int64_t n, int32_t n_bins, uint8_t* voiced, int32_t* bins,

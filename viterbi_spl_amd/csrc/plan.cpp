@@ -157,6 +157,49 @@ BandedPlan analyze_banded(const float* A, int S) {
     return bp;
 }
 
+void analyze_step(const float* A, int S, BandedPlan& bp) {
+    bp.step_ok = false;
+    const int n = S - 1, SP = bp.SP;
+    if (n < 128) return;
+    // band width and count from source column 0: runs of equal values over the voiced targets
+    int bw = 1;
+    while (bw < n && f2u(A[(size_t)bw * S]) == f2u(A[0])) ++bw;
+    if (bw < 4 || bw > 64) return;
+    int kb = 0;
+    for (int j = 0; j < n;) {
+        int r = j;
+        while (r < n && f2u(A[(size_t)r * S]) == f2u(A[(size_t)j * S])) ++r;
+        if (r == n) break;                     // the last run: the far value
+        if (r - j != bw) return;               // a near band that is not exactly bw wide
+        ++kb;
+        j = r;
+    }
+    if (kb < 1 || kb > kMaxStepBands || (kb + 1) * bw >= n) return;
+    std::vector<float> C((size_t)(kMaxStepBands + 1) * SP, -std::numeric_limits<float>::infinity());
+    std::vector<char> have((size_t)(kb + 1) * n, 0);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            const int d = i > j ? i - j : j - i;
+            const int k = std::min(d / bw, kb);
+            const float v = A[(size_t)j * S + i];
+            if (f2u(v) != f2u(v) || (f2u(v) & 0x7fffffffu) > 0x7f800000u) return;   // NaN
+            if (!have[(size_t)k * n + i]) { have[(size_t)k * n + i] = 1; C[(size_t)k * SP + i] = v; }
+            else if (f2u(C[(size_t)k * SP + i]) != f2u(v)) return;
+        }
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k <= kb; ++k) {
+            if (!have[(size_t)k * n + i]) C[(size_t)k * SP + i] = C[(size_t)kb * SP + i];   // band never reached from this source
+            if (!(C[(size_t)k * SP + i] >= C[(size_t)kb * SP + i])) return;                  // near bands must dominate the far value
+        }
+    for (int j = 1; j < n; ++j)
+        if (f2u(A[(size_t)j * S + n]) != f2u(A[n])) return;                               // unvoiced source: one value for all voiced targets
+    bp.step_bw = bw;
+    bp.step_kb = kb;
+    bp.step_cn = A[n];
+    bp.stepC = std::move(C);
+    bp.step_ok = true;
+}
+
 ImageLayout make_layout(int S, const BandedPlan& bp) {
     ImageLayout L;
     L.S = S;
@@ -178,6 +221,7 @@ ImageLayout make_layout(int S, const BandedPlan& bp) {
     L.off_lo2 = off;    off = align256(off + sizeof(int32_t) * L.SP);
     L.off_tabP = off;   off = align256(off + sizeof(float) * (size_t)std::max(L.W, 1) * L.SP);
     L.off_tabX = off;   off = align256(off + sizeof(float) * (size_t)(std::max(L.W, 1) + kMaxExtras + 1) * L.SP);
+    L.off_stepC = off;  off = align256(off + sizeof(float) * (size_t)(kMaxStepBands + 1) * L.SP);
     L.bytes = off;
     return L;
 }
@@ -212,6 +256,7 @@ void fill_image(const float* A, const float* log_pi, const BandedPlan& bp, const
     for (int d = 0; d < kMaxDenseRows; ++d) for (int j = 0; j < SP; ++j) da[(size_t)d * SP + j] = ninf;
     float* rc = reinterpret_cast<float*>(image + L.off_rowc);
     for (int j = 0; j < SP; ++j) rc[j] = 0.f;
+    if (bp.step_ok) std::memcpy(image + L.off_stepC, bp.stepC.data(), sizeof(float) * bp.stepC.size());
     if (!bp.ok) return;
     for (int j = 0; j < S; ++j) { lo[j] = bp.lo[j]; kind[j] = bp.kind[j]; rc[j] = bp.rowc[j]; }
     for (int w = 0; w < L.W; ++w)

@@ -47,7 +47,21 @@ struct BandedPlan {
     bool lo2_affine = false;  // lo2[p] == clamp(2p - lo2_off, 0, S - W)
     int lo2_off = 0;
     int lo_off = 0;
+
+    // "Step" structure (the Durrieu matrix of imm's own decoder; analyze_step): with n = S-1 voiced states, for voiced
+    // source i and voiced target j  logA_T[j][i] == stepC[min(|i-j| / step_bw, step_kb)][i]  -- column i is piecewise
+    // constant in distance bands of step_bw bins, constant from distance step_kb*step_bw on --, no near band of a column
+    // is below its far value, and the unvoiced source column is one value for every voiced target (step_cn).  Then
+    // fl(delta_i + logA_T[j][i]) takes only step_kb+1 values per source and the far sources reduce to ONE maximum.
+    bool step_ok = false;
+    int step_bw = 0, step_kb = 0;
+    std::vector<float> stepC;   // [(kMaxStepBands+1)][SP], rows > step_kb unused, -inf for i >= n
+    float step_cn = 0.f;
 };
+
+constexpr int kMaxStepBands = 15;
+// Fills the step_* fields of bp (bp.SP must be set: call after analyze_banded).
+void analyze_step(const float* logA_T, int S, BandedPlan& bp);
 
 // Analyse logA_T ([S,S] row-major, row j = into target j).
 BandedPlan analyze_banded(const float* logA_T, int S);
@@ -68,6 +82,7 @@ struct ImageLayout {
     size_t off_lo2 = 0;      // int32 [SP/2]        pair windows (pair_ok)
     size_t off_tabP = 0;     // float [W][SP]       tabP[w][j] = logA_T[j][lo2[j/2] + w]
     size_t off_tabX = 0;     // float [SP][W+5]     per target: W window entries, 4 extra-column entries, row constant (back-trace)
+    size_t off_stepC = 0;    // float [16][SP]      step-structure band values per source (step_ok)
     size_t bytes = 0;
 };
 

@@ -17,6 +17,7 @@ struct vph_plan {
 vph_plan* vph_create(const float* logA_T, const float* log_pi, int S) {
     vph_plan* p = new vph_plan();
     p->bp = vit::analyze_banded(logA_T, S);
+    if (!p->bp.ok) vit::analyze_step(logA_T, S, p->bp);
     p->L = vit::make_layout(S, p->bp);
     p->image.resize(p->L.bytes);
     vit::fill_image(logA_T, log_pi, p->bp, p->L, p->image.data());
@@ -29,7 +30,8 @@ void vph_info(const vph_plan* p, int* info, float* c0) {
     info[0] = p->bp.ok; info[1] = p->bp.S; info[2] = p->bp.SP; info[3] = p->bp.W;
     info[4] = p->bp.n_extras; info[5] = p->bp.n_dense; info[6] = p->bp.max_window;
     for (int k = 0; k < 4; ++k) { info[7 + k] = p->bp.extras[k]; info[11 + k] = p->bp.dense_rows[k]; }
-    info[15] = p->L.S4 | (p->bp.pair_ok ? 0x10000 : 0) | (p->bp.floor_ok ? 0x20000 : 0);
+    info[15] = p->L.S4 | (p->bp.pair_ok ? 0x10000 : 0) | (p->bp.floor_ok ? 0x20000 : 0) | (p->bp.step_ok ? 0x40000 : 0) |
+               ((p->bp.step_ok ? p->bp.step_kb : 0) << 20) | ((p->bp.step_ok ? p->bp.step_bw : 0) << 24);
     *c0 = p->bp.c0;
 }
 // offsets[0..11]: logpi, A4, lo, kind, tabA, extraA, denseA, total bytes, Arow, rowc, lo2, tabP

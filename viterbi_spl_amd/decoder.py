@@ -61,7 +61,7 @@ class ViterbiDecoder:
         _lib.check(lib.vit_plan_query(self._plan, ctypes.byref(info)), "vit_plan_query")
         self.info = {
             "S": int(info.S), "banded_ok": bool(info.banded_ok), "n_extras": int(info.n_extras),
-            "n_dense_rows": int(info.reserved[0]), "floor_ok": bool(info.reserved[1]), "lo_affine": bool(info.reserved[2] & 1), "pair_ok": bool(info.reserved[2] & 2), "max_window": int(info.max_window),
+            "n_dense_rows": int(info.reserved[0]), "floor_ok": bool(info.reserved[1]), "lo_affine": bool(info.reserved[2] & 1), "pair_ok": bool(info.reserved[2] & 2), "step_ok": bool(info.reserved[2] & 4), "max_window": int(info.max_window),
             "group_window": int(info.group_window), "row_constant": float(info.consts[0]),
             "extras": [int(info.extras[k]) for k in range(int(info.n_extras))],
         }
