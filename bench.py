@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--states", type=int, default=361)
     ap.add_argument("--algo", default="auto", choices=["auto", "dense", "banded"])
     ap.add_argument("--emissions", default="peaks", choices=["peaks", "dense"])
-    ap.add_argument("--transition", default="tonet", choices=["tonet", "dense"])
+    ap.add_argument("--transition", default="tonet", choices=["tonet", "dense", "durrieu"])
     ap.add_argument("--f16", action="store_true", help="store emissions as float16")
     ap.add_argument("--dmax", type=int, default=14, help="band half-width of the tonet-recipe transition (tonet 14, jdc 40, imm 56)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -66,6 +66,9 @@ def make_params(args):
     S = args.states
     if args.transition == "tonet":
         return synth.log_params(synth.tonet_transition(S - 1, args.dmax), synth.floored_prior(S))
+    if args.transition == "durrieu":   # imm's own decoder: dense, piecewise constant in 20-bin distance bands, uniform prior
+        A = synth.durrieu_transition(S - 1, 20)
+        return (np.require(np.log(A).astype(np.float32).T, np.float32, ["C"]), np.log(np.full(S, 1.0 / S)).astype(np.float32))
     return synth.dense_random_log_transition(S, seed=3), synth.dense_random_log_transition(S, seed=4)[0].copy()
 
 
@@ -117,7 +120,7 @@ def main():
     dec = ViterbiDecoder(logA_T, log_pi, dev)
     algo = args.algo
     if algo == "auto":
-        algo = "banded" if dec.info["banded_ok"] else "dense"
+        algo = "banded" if dec.info["banded_ok"] else "auto"      # "auto": the step-structured kernel if the plan proves it, else dense
     gen = synth.emissions_peaks if args.emissions == "peaks" else synth.emissions_dense
     dt = torch.float16 if args.f16 else torch.float32
     E = gen(B, T, S, seed=1234, device=dev, dtype=dt, first_song=rank * B)
@@ -232,7 +235,7 @@ def main():
             except Exception:
                 bt_traffic = None
         SD = (S + 5) // 4 * 4
-        fwd_kernel = "dense_forward_kernel"
+        fwd_kernel = "step_forward_kernel" if (dec.info["step_ok"] and args.algo == "auto") else "dense_forward_kernel"
         if algo == "banded":   # same rule as launch_banded_t (kernels.hip)
             nwt = next((w for w in (2, 4, 6, 8, 12) if w * 64 >= S), 0)
             floor_form = dec.info["floor_ok"] and dec.info["n_dense_rows"] == 0 and S < nwt * 64

@@ -255,6 +255,15 @@ int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* len
     b.off_tabA = plan->L.off_tabA;
     b.off_extraA = plan->L.off_extraA;
     b.off_tabX = plan->L.off_tabX;
+    b.off_stepC = plan->L.off_stepC;
+    b.step_ok = 0;
+    if (plan->bp.step_ok) {   // band = dist / bw as a multiply-shift, verified here for every distance that can occur
+        const int bw = plan->bp.step_bw;
+        const int mult = (65536 + bw - 1) / bw;
+        bool exact = true;
+        for (int d = 0; d < 1024 && exact; ++d) exact = ((unsigned)(d * mult) >> 16) == (unsigned)(d / bw);
+        if (exact) { b.step_ok = 1; b.step_kb = plan->bp.step_kb; b.step_mult = mult; b.step_cn = plan->bp.step_cn; }
+    }
     b.off_denseA = plan->L.off_denseA;
     b.off_Arow = plan->L.off_Arow;
     b.off_rowc = plan->L.off_rowc;

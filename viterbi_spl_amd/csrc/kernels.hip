@@ -1171,6 +1171,10 @@ __global__ void __launch_bounds__(512) banded_backtrace_kernel(BtArgs a) {
                 bt_fetch(stage, reinterpret_cast<const f32x4*>(hist + (size_t)nfirst * SD), (ntop - nfirst + 1) * rv, lane);
             }
             int outv = 0;
+            // MODE 1 re-chases a chunk whose assumed entry state was wrong: as soon as the new path meets the stored one the
+            // rest of the chunk is already right (the step below a state depends on that state only)
+            const int oldv = (MODE == 1 && lane < rows) ? states[first + lane] : -1;
+            int rstop = -1;
             int row_off = __builtin_amdgcn_readfirstlane(tile_off + (rows - 1) * SD);
             for (int r = __builtin_amdgcn_readfirstlane(rows - 1); r >= 0; --r, row_off -= SD) {
                 // row r of the tile = delta_t, t = first + r: decides the state at frame t from the state `cur` at t+1
@@ -1256,8 +1260,10 @@ __global__ void __launch_bounds__(512) banded_backtrace_kernel(BtArgs a) {
                 }
                 cur = (int)idx;
                 outv = lane == r ? cur : outv;
+                if (MODE == 1 && cur == __builtin_amdgcn_readlane(oldv, r)) { rstop = r; break; }
             }
-            if (write && lane < rows) states[first + lane] = outv;
+            if (write && lane < rows && lane > rstop) states[first + lane] = outv;
+            if (MODE == 1 && rstop >= 0) return __builtin_amdgcn_readfirstlane(states[bottom]);   // the stored path continues unchanged
             top = ntop;
         }
         return cur;
@@ -1350,6 +1356,13 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform for the compiler
+    // step-structured dense matrix (plan.step_ok): the (step_kb+1) x SP band table replaces the matrix rows in LDS
+    float* stepL = reinterpret_cast<float*>(loL);
+    const bool step = !banded && a.step_ok != 0;
+    if (step) {
+        const float* gs = reinterpret_cast<const float*>(a.image + a.off_stepC);
+        for (int k = tid; k < (a.step_kb + 1) * SP; k += kBtWaves * 64) stepL[k] = gs[k];
+    }
     if (banded) {
         const int32_t* gl = reinterpret_cast<const int32_t*>(a.image + a.off_lo);
         const int32_t* gk = reinterpret_cast<const int32_t*>(a.image + a.off_kind);
@@ -1415,6 +1428,8 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
             const int nfirst = ntop - K + 1 > bottom ? ntop - K + 1 : bottom;
             bt_fetch(stage, reinterpret_cast<const f32x4*>(hist + (size_t)nfirst * SD), (ntop - nfirst + 1) * rv, lane);
         }
+        const int oldv = (MODE == 1 && lane < rows) ? states[first + lane] : -1;   // see banded_backtrace_kernel
+        int rstop = -1;
         for (int r = rows - 1; r >= 0; --r) {
             const float* row = tile + r * SD;   // delta_t, t = first + r; decides the state at frame t
             const int jj = __builtin_amdgcn_readfirstlane(cur);  // path state at frame t+1 (wave-uniform)
@@ -1490,6 +1505,17 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
                         for (int q = 1; q < kMaxDenseRows; ++q) av = kd == q ? dA[q][e] : av;
                         vf[e] = d[e] + av;
                     }
+                } else if (step && jj < S - 1) {
+                    // voiced target of a step matrix: logA_T[jj][i] = stepC[min(|i-jj| / bw, kb)][i], unvoiced source: step_cn
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) {
+                        const int i = e * 64 + lane;
+                        const unsigned dist = (unsigned)(i > jj ? i - jj : jj - i);
+                        unsigned band = (dist * (unsigned)a.step_mult) >> 16;          // dist / step_bw (host-checked for dist < 1024)
+                        band = band < (unsigned)a.step_kb ? band : (unsigned)a.step_kb;
+                        const float wgt = i < S - 1 ? stepL[band * SP + i] : (i == S - 1 ? a.step_cn : -INFINITY);
+                        vf[e] = i < S ? d[e] + wgt : -INFINITY;
+                    }
                 } else {
 #pragma unroll
                     for (int e = 0; e < EPL; ++e) {
@@ -1522,9 +1548,12 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
                 cur = idx == 0x7fffffffu ? 0 : (int)idx;
             }
             if (lane == 0) out[r] = cur;
+            if (MODE == 1 && cur == __builtin_amdgcn_readlane(oldv, __builtin_amdgcn_readfirstlane(r))) { rstop = r; break; }
         }
         if (write)
-            for (int r = lane; r < rows; r += 64) states[first + r] = out[r];
+            for (int r = lane; r < rows; r += 64)
+                if (r > rstop) states[first + r] = out[r];
+        if (MODE == 1 && rstop >= 0) return __builtin_amdgcn_readfirstlane(states[bottom]);
         top = ntop;
     }
     return cur;
@@ -1789,6 +1818,7 @@ static hipError_t launch_bt_t(BtArgs a, hipStream_t st) {
         }
     }
     size_t lds = sizeof(f32x4) * kBtWaves * kBtVec * 64 + sizeof(int32_t) * kBtWaves * 64;
+    if (!a.banded && a.step_ok) lds += sizeof(float) * (a.step_kb + 1) * a.SP;
     if (a.banded) {
         const size_t tables = sizeof(int32_t) * 2 * a.SP + sizeof(float) * (1 + kMaxExtras + a.W) * a.SP;
         if (lds + tables + 1024 > kLdsBytes) {   // tables do not fit: evaluate full matrix rows instead (exact, slower)

@@ -75,7 +75,9 @@ struct BtArgs {
     int n_extras, n_dense;
     int extras[kMaxExtras];
     float c0;
-    size_t off_lo, off_kind, off_tabA, off_extraA, off_denseA, off_Arow, off_rowc, off_tabX;
+    size_t off_lo, off_kind, off_tabA, off_extraA, off_denseA, off_Arow, off_rowc, off_tabX, off_stepC;
+    int step_ok, step_kb, step_mult;   // step-structured dense matrix: band = min((dist * step_mult) >> 16, step_kb)
+    float step_cn;
 };
 
 hipError_t launch_dense(const FwdArgs& a, int songs_per_group, bool f16, hipStream_t st);
