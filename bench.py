@@ -235,7 +235,7 @@ def main():
             except Exception:
                 bt_traffic = None
         SD = (S + 5) // 4 * 4
-        fwd_kernel = "step_forward_kernel" if (dec.info["step_ok"] and args.algo == "auto") else "dense_forward_kernel"
+        fwd_kernel = "step4_forward_kernel" if (dec.info["step_ok"] and args.algo == "auto") else "dense_forward_kernel"
         if algo == "banded":   # same rule as launch_banded_t (kernels.hip)
             nwt = next((w for w in (2, 4, 6, 8, 12) if w * 64 >= S), 0)
             floor_form = dec.info["floor_ok"] and dec.info["n_dense_rows"] == 0 and S < nwt * 64

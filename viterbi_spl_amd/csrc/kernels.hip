@@ -387,6 +387,235 @@ __global__ void __launch_bounds__((NWV + 1) * 64) step_forward_kernel(FwdArgs a)
 }
 
 // ---------------------------------------------------------------------------------------
+// Step-structured forward kernel, four targets per lane (what runs for the Durrieu matrix).
+//
+// Same arithmetic as step_forward_kernel.  What bounds that kernel is the LDS return path (359 four-byte window reads
+// per target and frame).  With lane p owning states 4p .. 4p+3, the band windows of its four targets overlap in 17 of
+// 20 sources, start on 16-byte boundaries (BW is a multiple of 4) and are read as contiguous float4s -- the ideal LDS
+// pattern, a single copy of every V_k, 3.4x fewer bytes -- and the shared 17 sources are reduced once: ~15 instead of
+// 40 max3 per band side for the four targets.  Three voiced waves + the unvoiced wave: one wave per SIMD.
+// ---------------------------------------------------------------------------------------
+template <int BW, int KB, int PF, typename ET>
+__global__ void __launch_bounds__(256) step4_forward_kernel(FwdArgs a) {
+    static_assert(BW == 20 && PF % 2 == 0, "written for 20-bin bands");
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int NW4 = 3;                        // voiced waves: 192 lanes x 4 states
+    constexpr int NPV = NW4 * 256;                // padded voiced states
+    constexpr int PAD = KB * BW + BW;             // -inf margin on both sides of every V_k (multiple of 4)
+    constexpr int VLEN = NPV + 2 * PAD;
+    constexpr int DLEN = NPV + 64;
+    float* V = reinterpret_cast<float*>(smem);    // [2][KB][VLEN]
+    float* dl = V + 2 * KB * VLEN;                // [2][DLEN]  delta of the voiced states (for the unvoiced target's row)
+    float* wm = dl + 2 * DLEN;                    // [2][4]     wave maxima of V_KB, slot 3 = the unvoiced source's candidate
+    float* dun = wm + 2 * 4;                      // [2]        delta of the unvoiced state
+    VI* tot = reinterpret_cast<VI*>(dun + 2 + 2);
+    const int S = a.S, SP = a.SP, T = a.T, SD = a.SD;
+    const int n = S - 1;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int song = blockIdx.x;
+    const int Tb = song_length(a.lengths, song, T);
+    const ET* __restrict__ E = reinterpret_cast<const ET*>(a.logE) + (size_t)song * T * S;
+    float* __restrict__ hist = a.hist + (size_t)song * T * SD;
+    const float* __restrict__ lpi = reinterpret_cast<const float*>(a.image + a.off_logpi);
+
+    for (int k = tid; k < 2 * KB * VLEN + 2 * DLEN + 2 * 4 + 4; k += 256) V[k] = -INFINITY;
+    __syncthreads();
+
+    const bool voiced_wave = wv < NW4;
+    const int j0 = 4 * tid;                                               // voiced lanes: first of the four own states
+    bool val[4];
+    int col[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        val[q] = voiced_wave && j0 + q < n;
+        col[q] = voiced_wave ? (j0 + q < n ? j0 + q : n - 1) : n;          // emission column loaded (unvoiced wave: column n)
+    }
+    const bool all4 = voiced_wave && j0 + 3 < n;
+    f32x4 c[KB + 1];
+    {
+        const float* __restrict__ sc = reinterpret_cast<const float*>(a.image + a.off_stepC);
+#pragma unroll
+        for (int k = 0; k <= KB; ++k) {
+            c[k].x = val[0] ? sc[(size_t)k * SP + j0 + 0] : -INFINITY;
+            c[k].y = val[1] ? sc[(size_t)k * SP + j0 + 1] : -INFINITY;
+            c[k].z = val[2] ? sc[(size_t)k * SP + j0 + 2] : -INFINITY;
+            c[k].w = val[3] ? sc[(size_t)k * SP + j0 + 3] : -INFINITY;
+        }
+    }
+    constexpr int NQ = 13;                                                // sources per lane of the unvoiced target's wave
+    float rown[NQ];
+    {
+        const float* __restrict__ ar = reinterpret_cast<const float*>(a.image + a.off_Arow) + (size_t)n * SP;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) rown[q] = (!voiced_wave && lane + 64 * q < SP) ? ar[lane + 64 * q] : -INFINITY;
+    }
+    const float cn = a.step_cn;
+
+    auto load4 = [&](const int row) -> f32x4 {
+        const ET* __restrict__ r = E + (size_t)row * S;
+        return f32x4{load_e<ET>(r + col[0]), load_e<ET>(r + col[1]), load_e<ET>(r + col[2]), load_e<ET>(r + col[3])};
+    };
+    auto store4 = [&](const int row, const f32x4 d) {
+        float* __restrict__ h = hist + (size_t)row * SD;
+        if (all4) {
+            *reinterpret_cast<f32x4*>(h + j0) = d;
+        } else if (voiced_wave) {
+            if (val[0]) h[j0] = d.x;
+            if (val[1]) h[j0 + 1] = d.y;
+            if (val[2]) h[j0 + 2] = d.z;
+        } else if (lane == 0) {
+            h[n] = d.x;
+        }
+    };
+    const f32x4 ninf4 = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    auto mask4 = [&](const f32x4 d) -> f32x4 {
+        if (!voiced_wave) return d;
+        return f32x4{val[0] ? d.x : -INFINITY, val[1] ? d.y : -INFINITY, val[2] ? d.z : -INFINITY, val[3] ? d.w : -INFINITY};
+    };
+
+    f32x4 dn;                                                             // delta of the own states (unvoiced wave: .x = state n, every lane)
+    {
+        const f32x4 e0 = load4(0);
+        dn = mask4(f32x4{lpi[col[0]], lpi[col[1]], lpi[col[2]], lpi[col[3]]} + e0);
+        store4(0, dn);
+    }
+    f32x4 er[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) er[k] = load4(1 + k < Tb ? 1 + k : Tb - 1);
+
+    auto mx3 = [](float acc, float x, float y) { return fmaxf(fmaxf(acc, x), y); };
+
+    auto frame = [&](const int t, f32x4& e_slot, const int b) {
+        // ---- publish delta_{t-1} into buffer b
+        if (voiced_wave) {
+            float* vb = V + b * KB * VLEN + PAD + j0;
+#pragma unroll
+            for (int k = 0; k < KB; ++k) *reinterpret_cast<f32x4*>(vb + k * VLEN) = dn + c[k];
+            *reinterpret_cast<f32x4*>(dl + b * DLEN + j0) = dn;
+            const f32x4 vf = dn + c[KB];
+            const float inc = wave_scan_max(fmaxf(fmaxf(vf.x, vf.y), fmaxf(vf.z, vf.w)));
+            if (lane == 63) wm[b * 4 + wv] = inc;
+        } else if (lane == 0) {
+            dun[b] = dn.x;
+            wm[b * 4 + 3] = dn.x + cn;
+        }
+        __syncthreads();
+        // ---- consume
+        f32x4 m = ninf4;
+        if (voiced_wave) {
+            const float* rb = V + b * KB * VLEN + PAD + j0;                 // 16-byte aligned; offsets below are relative to state j0
+            // band 0: target q takes offsets q-19 .. q+19; read -20 .. 23 (11 float4), shared core -16 .. 19
+            {
+                float x[44];
+#pragma unroll
+                for (int u = 0; u < 11; ++u) {
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(rb - 20 + 4 * u);
+                    x[4 * u] = v4.x; x[4 * u + 1] = v4.y; x[4 * u + 2] = v4.z; x[4 * u + 3] = v4.w;
+                }
+                auto X = [&](int off) { return x[off + 20]; };
+                float core = -INFINITY;
+#pragma unroll
+                for (int o = -16; o + 1 <= 19; o += 2) core = mx3(core, X(o), X(o + 1));
+                m.x = mx3(fmaxf(core, X(-19)), X(-18), X(-17));
+                m.y = mx3(fmaxf(core, X(-18)), X(-17), X(20));
+                m.z = mx3(fmaxf(core, X(-17)), X(20), X(21));
+                m.w = mx3(fmaxf(core, X(20)), X(21), X(22));
+            }
+#pragma unroll
+            for (int k = 1; k < KB; ++k) {
+                const float* rk = rb + k * VLEN;
+                // right side: target q takes k*BW + q .. k*BW + q + 19; read k*BW .. k*BW + 23, shared core +3 .. +19
+                {
+                    float x[24];
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) {
+                        const f32x4 v4 = *reinterpret_cast<const f32x4*>(rk + k * BW + 4 * u);
+                        x[4 * u] = v4.x; x[4 * u + 1] = v4.y; x[4 * u + 2] = v4.z; x[4 * u + 3] = v4.w;
+                    }
+                    float core = x[3];
+#pragma unroll
+                    for (int o = 4; o + 1 <= 19; o += 2) core = mx3(core, x[o], x[o + 1]);
+                    m.x = fmaxf(m.x, mx3(fmaxf(core, x[0]), x[1], x[2]));
+                    m.y = fmaxf(m.y, mx3(fmaxf(core, x[1]), x[2], x[20]));
+                    m.z = fmaxf(m.z, mx3(fmaxf(core, x[2]), x[20], x[21]));
+                    m.w = fmaxf(m.w, mx3(fmaxf(core, x[20]), x[21], x[22]));
+                }
+                // left side: target q takes q - k*BW - 19 .. q - k*BW; read -k*BW - 20 .. -k*BW + 3, shared core -16 .. 0 (rel. -k*BW)
+                {
+                    float x[24];
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) {
+                        const f32x4 v4 = *reinterpret_cast<const f32x4*>(rk - k * BW - 20 + 4 * u);
+                        x[4 * u] = v4.x; x[4 * u + 1] = v4.y; x[4 * u + 2] = v4.z; x[4 * u + 3] = v4.w;
+                    }
+                    auto X = [&](int off) { return x[off + 20]; };            // off relative to -k*BW
+                    float core = X(-16);
+#pragma unroll
+                    for (int o = -15; o + 1 <= 0; o += 2) core = mx3(core, X(o), X(o + 1));
+                    m.x = fmaxf(m.x, mx3(fmaxf(core, X(-19)), X(-18), X(-17)));
+                    m.y = fmaxf(m.y, mx3(fmaxf(core, X(-18)), X(-17), X(1)));
+                    m.z = fmaxf(m.z, mx3(fmaxf(core, X(-17)), X(1), X(2)));
+                    m.w = fmaxf(m.w, mx3(fmaxf(core, X(1)), X(2), X(3)));
+                }
+            }
+            // the far sources and the unvoiced source: one maximum
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wm + b * 4);
+            const float M = fmaxf(fmaxf(w.x, w.y), fmaxf(w.z, w.w));
+            m = f32x4{fmaxf(m.x, M), fmaxf(m.y, M), fmaxf(m.z, M), fmaxf(m.w, M)};
+        } else {
+            // the unvoiced target: every source through its own (arbitrary) row
+            float mm = -INFINITY;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int i = lane + 64 * q;
+                const float d = i < n ? dl[b * DLEN + i] : (i == n ? dun[b] : -INFINITY);
+                mm = fmaxf(mm, d + rown[q]);
+            }
+            m.x = wave_max_all(mm);
+        }
+        dn = mask4(m + e_slot);
+        const int tn = t + PF < Tb ? t + PF : Tb - 1;
+        store4(t, dn);
+        e_slot = load4(tn);
+    };
+    int t = 1;
+    for (; t + PF - 1 < Tb; t += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) frame(t + k, er[k], (k + 1) & 1);
+    }
+#pragma unroll
+    for (int k = 0; k < PF - 1; ++k)
+        if (t + k < Tb) frame(t + k, er[k], (k + 1) & 1);
+
+    // terminal state: lowest-index argmax; a voiced lane holds four adjacent states
+    __syncthreads();
+    {
+        VI x = vi_identity();
+        if (voiced_wave) {
+            if (val[0]) x = VI{dn.x, j0};
+            if (val[1]) x = op_fwd(x, VI{dn.y, j0 + 1});
+            if (val[2]) x = op_fwd(x, VI{dn.z, j0 + 2});
+            if (val[3]) x = op_fwd(x, VI{dn.w, j0 + 3});
+        } else if (lane == 0) {
+            x = VI{dn.x, n};
+        }
+        x = wave_scan<false>(x);
+        if (lane == 63) tot[wv] = x;
+        __syncthreads();
+        if (tid == 0) {
+            VI acc = vi_identity();
+            for (int bq = 0; bq < 4; ++bq) acc = op_fwd(acc, tot[bq]);
+            if (acc.i == kBig) acc.i = 0;
+            a.last_state[song] = acc.i;
+            if (a.loglik) a.loglik[song] = acc.v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Banded forward kernel: one song per workgroup, value-only.
 //
 // For a banded target j (window [lo_j, lo_j+W), row constant c_j, extra columns X):
@@ -1659,6 +1888,15 @@ hipError_t launch_step(const FwdArgs& a, bool f16, hipStream_t st) {
     if (!step_kernel_instantiated(a.S, a.step_bw, a.step_kb)) return hipErrorInvalidConfiguration;
     constexpr int VLEN = NWV * 64 + 2 * (KB * BW + BW);
     const size_t lds = sizeof(float) * (2 * KB * VLEN + 2 * (NWV * 64 + 64) + 2 * 16) + sizeof(VI) * 16;
+    if (!(a.debug & 32768)) {   // four targets per lane (32768 selects the one-target form for A/B)
+        constexpr int VL4 = 768 + 2 * (KB * BW + BW);
+        const size_t lds4 = sizeof(float) * (2 * KB * VL4 + 2 * (768 + 64) + 2 * 4 + 4) + sizeof(VI) * 16;
+        if (f16)
+            hipLaunchKernelGGL((step4_forward_kernel<BW, KB, PF, __half>), dim3((int)a.B), dim3(256), lds4, st, a);
+        else
+            hipLaunchKernelGGL((step4_forward_kernel<BW, KB, PF, float>), dim3((int)a.B), dim3(256), lds4, st, a);
+        return hipGetLastError();
+    }
     if (f16)
         hipLaunchKernelGGL((step_forward_kernel<BW, KB, NWV, PF, __half>), dim3((int)a.B), dim3((NWV + 1) * 64), lds, st, a);
     else
