@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VIT_ABI_VERSION 1
+#define VIT_ABI_VERSION 2
 
 typedef enum vit_status {
     VIT_OK = 0,
@@ -60,7 +60,10 @@ typedef enum vit_dtype { VIT_F32 = 0, VIT_F16 = 1 } vit_dtype;
 typedef enum vit_algo {
     VIT_ALGO_AUTO = 0,   /* banded if the plan proved the structure, else dense */
     VIT_ALGO_DENSE = 1,  /* S*S max-plus per frame, any matrix */
-    VIT_ALGO_BANDED = 2  /* exact row-constant + window + extra-column decomposition */
+    VIT_ALGO_BANDED = 2, /* exact row-constant + window + extra-column decomposition; the form (one song per
+                            workgroup / one song per wavefront) is chosen from the batch size */
+    VIT_ALGO_WAVE = 3,   /* banded, one song per wavefront (throughput form; VIT_EUNSUPPORTED if the plan lacks it) */
+    VIT_ALGO_GROUP = 4   /* banded, one song per workgroup (latency form) */
 } vit_algo;
 
 typedef struct vit_plan vit_plan; /* opaque: analysed transition matrix + prior */
@@ -73,7 +76,7 @@ typedef struct vit_plan_info {
     int32_t n_extras;       /* extra exception columns shared by most rows */
     int32_t max_window;     /* widest per-row exception window */
     int32_t group_window;   /* window width the banded kernel evaluates per target */
-    int32_t reserved[3];    /* [0] dense rows, [1] one-maximum ("floor") form proven, [2] bit 0: window start affine in the target, bit 1: pair windows proven, bit 2: step structure (dense matrix, piecewise-constant columns) */
+    int32_t reserved[3];    /* [0] dense rows, [1] one-maximum ("floor") form proven, [2] bit 0: window start affine in the target, bit 1: pair windows proven, bit 2: step structure (dense matrix, piecewise-constant columns), bit 3: wave form (one song per wavefront) available */
     float consts[4];
     int32_t extras[4];
 } vit_plan_info;
@@ -95,14 +98,31 @@ int vit_plan_create(const float *logA_T, const float *log_pi, int64_t S, vit_pla
 void vit_plan_destroy(vit_plan *plan);
 int vit_plan_query(const vit_plan *plan, vit_plan_info *info);
 
+/*
+ * Kernel-selection overrides, per plan.  Every setting decodes the same bits -- they exist so that tests and timing
+ * scripts can reach each kernel form (the library reads NO environment variables).  Keys:
+ *   "forward_form"     banded plans: 0 by batch size | 1 one target per lane | 2 two targets per lane | 3 scan form |
+ *                      4 wave form | 5 never the wave form
+ *   "backtrace_form"   0 auto | 1 generic kernel
+ *   "dense_songs"      songs per workgroup of the dense kernel (0 auto); "dense_one_thread" 1 = one thread per target
+ *   "step_form"        step-structured kernel: 0 four targets per lane | 1 one | 2 off (plain dense kernel)
+ *   "bt_chunks", "bt_warm"   time-parallel back-trace: chunks per song (0 auto), warm-up frames (-1 default)
+ *   "win_shift"        LDS window shift 0..3 (-1 from the plan); "wave_min_batch" (0 default), "wave_two" 1
+ *   "timing"           ablation / probe mask: accepted only by a -DVIT_TIMING_HOOKS build (VIT_EUNSUPPORTED otherwise;
+ *                      those bits change results)
+ *   "reset"            back to the defaults
+ * Not thread-safe against concurrent decodes on the same plan.
+ */
+int vit_plan_set_option(vit_plan *plan, const char *key, int64_t value);
+
 /* Device image of the plan: the caller allocates vit_plan_image_bytes() bytes of
  * device memory (256-byte aligned) and uploads once; the copy is enqueued on `stream`. */
 size_t vit_plan_image_bytes(const vit_plan *plan);
 int vit_plan_upload(vit_plan *plan, void *device_image, size_t bytes, vit_stream stream);
 
 /* Bytes of device workspace vit_decode() needs for a [B,T,S] batch (float32 delta history
- * [B,T,SD], SD = ceil((S+2)/4)*4, whose pad column S holds the per-frame maximum + per-song terminals).  256-byte aligned
- * base required. */
+ * [B,T,SD] + per-song terminals; SD = ceil((S+2)/4)*4 with the per-frame maximum in pad column S, or 64*ceil(S/64) in slot
+ * order for the wave form -- the size covers whichever form runs).  256-byte aligned base required. */
 size_t vit_workspace_bytes(const vit_plan *plan, int64_t B, int64_t T);
 
 /*
@@ -118,9 +138,11 @@ int vit_decode(const vit_plan *plan, const void *logE, int emis_dtype, int64_t B
                const int64_t *lengths, void *workspace, size_t workspace_bytes,
                int32_t *states, float *loglik, int algo, vit_stream stream);
 
-/* Forward pass only / back-trace only; used by bench.py to time the two kernels separately.
- * vit_decode() == forward then backtrace.  `algo` of vit_backtrace must be the one given to the
- * vit_forward that filled the workspace. */
+/* Forward pass only / back-trace only; used by bench.py to time the two kernels separately and to run the back-trace
+ * of one batch on another stream.  vit_decode() == forward then backtrace.  vit_forward records, per plan and workspace
+ * pointer, which kernel family filled the workspace and how its history rows are laid out; vit_backtrace reads that
+ * record (its `algo` argument is ignored) and returns VIT_EINVAL when this workspace has no forward pass of the same
+ * (B, T) on record.  The caller orders the two calls (same stream, or an event). */
 int vit_forward(const vit_plan *plan, const void *logE, int emis_dtype, int64_t B, int64_t T,
                 const int64_t *lengths, void *workspace, size_t workspace_bytes,
                 float *loglik, int algo, vit_stream stream);

@@ -22,6 +22,7 @@ def _lib():
     lib.vph_info.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.vph_offsets.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.vph_image.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.vph_wave.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     return lib
 
 
@@ -39,7 +40,11 @@ class HostPlan:
         lib.vph_offsets(h, off.ctypes.data)
         img = np.zeros(int(off[7]), np.uint8)
         lib.vph_image(h, img.ctypes.data)
+        wv = np.zeros(6, np.int64)
+        lib.vph_wave(h, wv.ctypes.data)
         lib.vph_destroy(h)
+        self.wave_ok, self.wave_npl, self.wave_d, self.wave_dk = bool(wv[0]), int(wv[1]), int(wv[2]), int(wv[3])
+        self.floor_all_ok = bool(wv[4])
         self.ok, self.S, self.SP, self.W = bool(info[0]), int(info[1]), int(info[2]), int(info[3])
         self.n_extras, self.n_dense, self.max_window = int(info[4]), int(info[5]), int(info[6])
         self.extras = [int(x) for x in info[7:7 + self.n_extras]]
@@ -66,6 +71,9 @@ class HostPlan:
         self.rowc = sec(9, np.float32, SP)
         self.lo2 = sec(10, np.int32, SP // 2)
         self.tabP = sec(11, np.float32, max(self.W, 1) * SP).reshape(max(self.W, 1), SP)
+        if self.wave_ok:   # [own state k][pair m][half h][lane]
+            n = self.wave_npl * (self.wave_dk + 1) * 2 * 64
+            self.tabV = img[int(wv[5]): int(wv[5]) + 4 * n].view(np.float32).reshape(self.wave_npl, self.wave_dk + 1, 2, 64)
 
 
 def replay_banded(plan: HostPlan, logE, floor=False, pair=False):
@@ -150,6 +158,60 @@ def replay_banded(plan: HostPlan, logE, floor=False, pair=False):
         path[t] = s
     replay_banded.last_fast_fraction = n_fast / max(T - 1, 1)
     return path, delta[path[-1]], delta
+
+
+def replay_wave(plan: HostPlan, logE):
+    """Follows wave_forward_kernel (viterbi_spl_amd/csrc/wave.hip) on the host, driven by the packed tabV table.
+
+    Slot q = npl*lane + k holds state q - o (o = 64*npl - S).  Own state k of lane l evaluates the dk+1 source pairs at
+    neighbourhood positions p0e(k) + 2m + h, i.e. slots npl*(l - H) + p; a slot outside the wave delivers 0 (the DPP shift's
+    bound_ctrl fill) -- its weight must be -inf.  m_j = max(window candidates, fl(M + c_j), extra-column candidates) with
+    M over ALL sources.  Returns (history [T, 64*npl] in the kernel's slot order incl. M in column 0, final delta [S])."""
+    assert plan.ok and plan.wave_ok and plan.floor_all_ok
+    S, npl, dk = plan.S, plan.wave_npl, plan.wave_dk
+    H = (dk + npl - 1) // npl
+    NQ = 64 * npl
+    o = NQ - S
+    logE = np.ascontiguousarray(logE, np.float32)
+    T = logE.shape[0]
+    ninf = np.float32(-np.inf)
+    lane = np.arange(NQ) // npl
+    k = np.arange(NQ) % npl
+    p0e = (k + npl * H - dk) & ~1
+    m = np.arange(dk + 1)
+    src_slot = (npl * (lane - H) + p0e)[:, None, None] + 2 * m[None, :, None] + np.arange(2)[None, None, :]   # [NQ, dk+1, 2]
+    w = plan.tabV[k[:, None, None], m[None, :, None], np.arange(2)[None, None, :], lane[:, None, None]]        # [NQ, dk+1, 2]
+    inside = (src_slot >= 0) & (src_slot < NQ)
+    assert np.all(np.isneginf(w[~inside])), "a source slot outside the wave must carry a -inf weight"
+    state = np.arange(NQ) - o
+    valid = state >= 0
+    assert np.all(np.isneginf(w[~valid])), "idle targets carry -inf weights"
+    # the table holds the true matrix entries: window positions that exist
+    cj = np.where(valid, plan.rowc[np.clip(state, 0, S - 1)], ninf).astype(np.float32)
+    xa = [np.where(valid, plan.extraA[e, np.clip(state, 0, S - 1)], ninf).astype(np.float32) for e in range(plan.n_extras)]
+    lpi = np.where(valid, plan.log_pi[np.clip(state, 0, S - 1)], ninf).astype(np.float32)
+    sc = np.clip(src_slot, 0, NQ - 1)
+
+    hist = np.empty((T, NQ), np.float32)
+    d = np.full(NQ, ninf, np.float32)
+    d[valid] = (lpi[valid] + logE[0]).astype(np.float32)
+    with np.errstate(invalid="ignore"):
+        for t in range(T):
+            if t > 0:
+                dz = np.where(inside, d[sc], np.float32(0))                    # 0 where a shift has no source lane
+                cand = (dz + w).astype(np.float32)
+                acc = np.max(cand.reshape(NQ, -1), axis=1)
+                mm = np.maximum(acc, (M + cj).astype(np.float32))
+                for e, x in enumerate(plan.extras):
+                    mm = np.maximum(mm, (d[o + x] + xa[e]).astype(np.float32))
+                e_t = np.full(NQ, np.float32(0))                               # idle slots: whatever the clamped load returns
+                e_t[valid] = logE[t]
+                d = (mm + e_t).astype(np.float32)
+                assert np.all(np.isneginf(d[~valid]))
+            M = np.max(d)
+            hist[t] = d
+            hist[t, 0] = M
+    return hist, d[valid].copy()
 
 
 def replay_dense_image(plan: HostPlan, logE):

@@ -36,7 +36,8 @@ def test_header_and_loader_agree(lib):
 
 
 def test_version_and_status_strings(lib):
-    assert lib.vit_abi_version() == 1
+    from viterbi_spl_amd import _lib
+    assert lib.vit_abi_version() == _lib.ABI_VERSION == 2
     assert lib.vit_status_string(0) == b"ok"
     assert b"workspace" in lib.vit_status_string(-4)
 
@@ -51,9 +52,17 @@ def test_plan_create_query_is_host_only(lib, golden):
     assert lib.vit_plan_query(plan, ctypes.byref(info)) == 0
     assert info.S == 361 and info.banded_ok == 1 and info.group_window == 32 and info.max_window == 29
     assert info.n_extras == 1 and info.extras[0] == 360
+    assert info.reserved[2] & 8          # the wave form (one song per wavefront) is available for the tonet matrix
     assert lib.vit_plan_image_bytes(plan) > 361 * 361 * 4
     ws = lib.vit_workspace_bytes(plan, 128, 30000)
-    assert ws >= 128 * 30000 * 364 * 4   # float32 delta history, rows padded to 16 bytes (+ >= 1 pad column)
+    assert ws >= 128 * 30000 * 384 * 4   # float32 delta history; the wave form's slot-order rows (64 * 6 floats) are the widest
+    # selection overrides: known keys only, and the result-breaking timing mask is refused by the release build
+    assert lib.vit_plan_set_option(plan, b"forward_form", 4) == 0
+    assert lib.vit_plan_set_option(plan, b"bt_chunks", 7) == 0
+    assert lib.vit_plan_set_option(plan, b"no_such_key", 1) == -1
+    assert lib.vit_plan_set_option(plan, b"timing", 1) == -5
+    assert lib.vit_plan_set_option(plan, b"timing", 0) == 0
+    assert lib.vit_plan_set_option(plan, b"reset", 0) == 0
     # decode before upload is refused, not executed
     dummy = ctypes.c_void_p(256 * 1024)
     rc = lib.vit_decode(plan, dummy, 0, 1, 10, None, dummy, ws, dummy, None, 0, None)

@@ -14,13 +14,14 @@ LIB_PATH = os.path.join(_PKG, "libviterbi_hip.so")
 
 VIT_OK = 0
 VIT_F32, VIT_F16 = 0, 1
-ALGO = {"auto": 0, "dense": 1, "banded": 2}
+ALGO = {"auto": 0, "dense": 1, "banded": 2, "wave": 3, "group": 4}
 
 EXPORTS = (
     "vit_abi_version", "vit_status_string", "vit_last_hip_error", "vit_plan_create", "vit_plan_destroy",
     "vit_plan_query", "vit_plan_image_bytes", "vit_plan_upload", "vit_workspace_bytes", "vit_decode",
-    "vit_forward", "vit_backtrace", "vit_voicing_map", "vit_obs_shaun", "vit_obs_softmax",
+    "vit_forward", "vit_backtrace", "vit_voicing_map", "vit_obs_shaun", "vit_obs_softmax", "vit_plan_set_option",
 )
+ABI_VERSION = 2
 
 
 class PlanInfo(ctypes.Structure):
@@ -68,6 +69,8 @@ def load() -> ctypes.CDLL:
     lib.vit_plan_destroy.argtypes = [vp]
     lib.vit_plan_query.restype = i32
     lib.vit_plan_query.argtypes = [vp, ctypes.POINTER(PlanInfo)]
+    lib.vit_plan_set_option.restype = i32
+    lib.vit_plan_set_option.argtypes = [vp, ctypes.c_char_p, i64]
     lib.vit_plan_image_bytes.restype = sz
     lib.vit_plan_image_bytes.argtypes = [vp]
     lib.vit_plan_upload.restype = i32

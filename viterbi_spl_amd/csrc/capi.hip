@@ -3,12 +3,41 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "../../include/viterbi_hip.h"
 #include "kernels.hpp"
 #include "plan.hpp"
+
+// Kernel-selection overrides (vit_plan_set_option).  Every combination decodes the same bits; they exist so that tests and
+// timing scripts can reach each kernel form.  `timing` carries the ablation / probe mask of a -DVIT_TIMING_HOOKS build and
+// is refused by a release build (those bits DO change results).
+struct Tuning {
+    int forward_form = 0;      // banded plans: 0 by batch size | 1 one target per lane | 2 two targets per lane | 3 scan form
+                               //               | 4 wave form (one song per wavefront) | 5 never the wave form
+    int backtrace_form = 0;    // 0 auto | 1 generic (lazy) kernel
+    int dense_songs = 0;       // songs per workgroup of the dense kernel (0 = by batch size)
+    int dense_one_thread = 0;  // 1: one thread per target in the dense kernel even where two fit
+    int step_form = 0;         // step-structured kernel: 0 four targets per lane | 1 one | 2 never (plain dense kernel)
+    int bt_chunks = 0;         // time-parallel back-trace: chunks per song (0 = auto)
+    int bt_warm = -1;          //                            warm-up frames (-1 = default)
+    int win_shift = -1;        // LDS window shift of the floor kernels (-1 = from the plan)
+    int wave_min_batch = 0;    // batch size from which banded plans take the wave form (0 = default)
+    int wave_two = 0;          // 1: always the two-waves-per-SIMD instantiation of the wave kernel
+    int timing = 0;
+};
+
+// What the last vit_forward left in a workspace: vit_backtrace reads the layout from here, not from its arguments.
+struct FwdStamp {
+    const void* ws = nullptr;
+    int64_t B = 0, T = 0;
+    int family = 0;            // 1 dense / step, 2 banded (one song per workgroup), 3 wave
+    int SD = 0, col0 = 0, mcol = 0;
+    int have_fmax = 0;         // column mcol of every history row holds a bound on max_i delta_t[i]
+};
 
 struct vit_plan {
     int S = 0;
@@ -16,6 +45,9 @@ struct vit_plan {
     vit::ImageLayout L;
     std::vector<uint8_t> host_image;
     const uint8_t* dev_image = nullptr;
+    Tuning tune;
+    mutable std::mutex mu;
+    mutable std::vector<FwdStamp> stamps;   // most recent first, at most kMaxStamps
 };
 
 namespace {
@@ -24,6 +56,28 @@ thread_local int g_last_hip_error = 0;
 
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 inline int hist_stride(int S) { return (S + 5) / 4 * 4; }   // rows 16-byte aligned, at least two pad columns (frame max, scratch)
+// widest history row any forward kernel of this plan writes (the wave form stores rows in slot order: 64 * npl floats)
+inline int hist_stride_ws(const vit_plan* p) {
+    const int sd = hist_stride(p->S);
+    const int sw = (p->bp.ok && p->bp.wave_ok) ? vit::wave_hist_stride(p->bp.wave_npl) : 0;
+    return sd > sw ? sd : sw;
+}
+constexpr size_t kMaxStamps = 16;
+constexpr int kWaveMinBatch = 384;   // from here on one song per wavefront beats one song per workgroup
+
+void stamp_put(const vit_plan* p, const FwdStamp& st) {
+    std::lock_guard<std::mutex> g(p->mu);
+    for (size_t k = 0; k < p->stamps.size(); ++k)
+        if (p->stamps[k].ws == st.ws) { p->stamps.erase(p->stamps.begin() + k); break; }
+    p->stamps.insert(p->stamps.begin(), st);
+    if (p->stamps.size() > kMaxStamps) p->stamps.pop_back();
+}
+bool stamp_get(const vit_plan* p, const void* ws, FwdStamp* out) {
+    std::lock_guard<std::mutex> g(p->mu);
+    for (const FwdStamp& st : p->stamps)
+        if (st.ws == ws) { *out = st; return true; }
+    return false;
+}
 
 int hip_fail(hipError_t e) {
     g_last_hip_error = (int)e;
@@ -34,10 +88,10 @@ struct WsLayout {
     size_t off_hist, off_fmax, off_last, off_entry, bytes;
 };
 
-WsLayout ws_layout(int S, int64_t B, int64_t T) {
+WsLayout ws_layout(const vit_plan* p, int64_t B, int64_t T) {
     WsLayout w;
     w.off_hist = 0;
-    w.off_fmax = align256((size_t)B * (size_t)T * hist_stride(S) * sizeof(float));
+    w.off_fmax = align256((size_t)B * (size_t)T * hist_stride_ws(p) * sizeof(float));
     w.off_last = w.off_fmax + align256((size_t)B * 64 * sizeof(float));   // timing-experiment scratch
     w.off_entry = w.off_last + align256((size_t)B * sizeof(int32_t));
     w.bytes = w.off_entry + align256((size_t)B * vit::kBtMaxChunks * sizeof(int32_t));
@@ -48,7 +102,7 @@ int check_common(const vit_plan* plan, int64_t B, int64_t T, const void* ws, siz
     if (!plan || !ws) return VIT_EINVAL;
     if (B < 0 || T < 1 || T > (int64_t)1 << 30 || B > (int64_t)1 << 30) return VIT_EINVAL;
     if (!plan->dev_image) return VIT_ENOTUPLOADED;
-    if (ws_bytes < ws_layout(plan->S, B, T).bytes) return VIT_EWORKSPACE;
+    if (ws_bytes < ws_layout(plan, B, T).bytes) return VIT_EWORKSPACE;
     if (((uintptr_t)ws & 255) != 0) return VIT_EINVAL;
     return VIT_OK;
 }
@@ -108,7 +162,8 @@ int vit_plan_query(const vit_plan* plan, vit_plan_info* info) {
     info->reserved[0] = plan->bp.n_dense;
     info->reserved[1] = plan->bp.ok && plan->bp.floor_ok ? 1 : 0;
     info->reserved[2] = (plan->bp.ok && plan->bp.lo_affine ? 1 : 0) | (plan->bp.ok && plan->bp.pair_ok ? 2 : 0) |
-                        (plan->bp.step_ok && vit::step_kernel_instantiated(plan->S, plan->bp.step_bw, plan->bp.step_kb) ? 4 : 0);
+                        (plan->bp.step_ok && vit::step_kernel_instantiated(plan->S, plan->bp.step_bw, plan->bp.step_kb) ? 4 : 0) |
+                        (plan->bp.ok && plan->bp.wave_ok ? 8 : 0);
     info->consts[0] = plan->bp.c0;
     for (int k = 0; k < vit::kMaxExtras; ++k) info->extras[k] = k < plan->bp.n_extras ? plan->bp.extras[k] : -1;
     return VIT_OK;
@@ -128,17 +183,51 @@ int vit_plan_upload(vit_plan* plan, void* device_image, size_t bytes, vit_stream
 
 size_t vit_workspace_bytes(const vit_plan* plan, int64_t B, int64_t T) {
     if (!plan || B < 0 || T < 1) return 0;
-    return ws_layout(plan->S, B, T).bytes;
+    return ws_layout(plan, B, T).bytes;
 }
 
-static int resolve_algo(const vit_plan* plan, int algo) {
+// options of vit_plan_set_option
+static int* tuning_field(Tuning& t, const char* key) {
+    struct { const char* k; int Tuning::*f; } const tab[] = {
+        {"forward_form", &Tuning::forward_form}, {"backtrace_form", &Tuning::backtrace_form},
+        {"dense_songs", &Tuning::dense_songs}, {"dense_one_thread", &Tuning::dense_one_thread},
+        {"step_form", &Tuning::step_form}, {"bt_chunks", &Tuning::bt_chunks}, {"bt_warm", &Tuning::bt_warm},
+        {"win_shift", &Tuning::win_shift}, {"wave_min_batch", &Tuning::wave_min_batch}, {"wave_two", &Tuning::wave_two},
+        {"timing", &Tuning::timing},
+    };
+    for (const auto& e : tab)
+        if (std::strcmp(e.k, key) == 0) return &(t.*(e.f));
+    return nullptr;
+}
+
+int vit_plan_set_option(vit_plan* plan, const char* key, int64_t value) {
+    if (!plan || !key) return VIT_EINVAL;
+    if (std::strcmp(key, "reset") == 0) { plan->tune = Tuning(); return VIT_OK; }
+    int* f = tuning_field(plan->tune, key);
+    if (!f || value < -1 || value > (int64_t)1 << 30) return VIT_EINVAL;
+#ifndef VIT_TIMING_HOOKS
+    if (f == &plan->tune.timing && value != 0) return VIT_EUNSUPPORTED;   // result-breaking ablations: timing builds only
+#endif
+    *f = (int)value;
+    return VIT_OK;
+}
+
+// forward kernel family for (plan, algo, batch): 1 dense / step, 2 banded one song per workgroup, 3 wave; < 0 = status
+static int resolve_family(const vit_plan* plan, int algo, int64_t B) {
     const int nwt = vit::banded_waves_for(plan->S);
-    const bool banded_possible = plan->bp.ok && (vit::scan_form_instantiated(plan->bp.W, nwt) ||
-                                                 (plan->bp.floor_ok && plan->S < nwt * 64 && vit::floor_form_instantiated(plan->bp.W, nwt)));
-    if (algo == VIT_ALGO_AUTO) return banded_possible ? VIT_ALGO_BANDED : VIT_ALGO_DENSE;
-    if (algo == VIT_ALGO_BANDED) return banded_possible ? VIT_ALGO_BANDED : VIT_EUNSUPPORTED;
-    if (algo == VIT_ALGO_DENSE) return VIT_ALGO_DENSE;
-    return VIT_EINVAL;
+    const bool group_ok = plan->bp.ok && (vit::scan_form_instantiated(plan->bp.W, nwt) ||
+                                          (plan->bp.floor_ok && plan->S < nwt * 64 && vit::floor_form_instantiated(plan->bp.W, nwt)));
+    const bool wave_ok = plan->bp.ok && plan->bp.wave_ok;
+    const int ff = plan->tune.forward_form;
+    const int64_t wmin = plan->tune.wave_min_batch > 0 ? plan->tune.wave_min_batch : kWaveMinBatch;
+    if (algo == VIT_ALGO_DENSE) return 1;
+    if (algo == VIT_ALGO_WAVE) return wave_ok ? 3 : VIT_EUNSUPPORTED;
+    if (algo == VIT_ALGO_GROUP) return group_ok ? 2 : VIT_EUNSUPPORTED;
+    if (algo != VIT_ALGO_AUTO && algo != VIT_ALGO_BANDED) return VIT_EINVAL;
+    const bool want_wave = wave_ok && ff != 5 && (ff == 4 || (ff == 0 && B >= wmin) || !group_ok);
+    if (want_wave) return 3;
+    if (group_ok) return 2;
+    return algo == VIT_ALGO_AUTO ? 1 : VIT_EUNSUPPORTED;
 }
 
 int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t B, int64_t T,
@@ -148,12 +237,12 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
     if (rc != VIT_OK) return rc;
     if (!logE) return VIT_EINVAL;
     if (emis_dtype != VIT_F32 && emis_dtype != VIT_F16) return VIT_EINVAL;
+    const int family = resolve_family(plan, algo, B);
+    if (family < 0) return family;
     if (B == 0) return VIT_OK;
-    const int requested = algo;
-    algo = resolve_algo(plan, algo);
-    if (algo < 0) return algo;
+    const Tuning& tn = plan->tune;
 
-    const WsLayout w = ws_layout(plan->S, B, T);
+    const WsLayout w = ws_layout(plan, B, T);
     uint8_t* ws = static_cast<uint8_t*>(workspace);
     vit::FwdArgs a{};
     a.image = plan->dev_image;
@@ -174,7 +263,10 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
     a.n_dense = plan->bp.ok ? plan->bp.n_dense : 0;
     for (int k = 0; k < vit::kMaxExtras; ++k) a.extras[k] = plan->bp.extras[k];
     a.c0 = plan->bp.c0;
-    if (const char* dbg = std::getenv("VIT_DEBUG_FLAGS")) a.debug = std::atoi(dbg);  // timing experiments only
+    a.debug = tn.timing;          // 0 unless built with -DVIT_TIMING_HOOKS (vit_plan_set_option refuses it otherwise)
+    a.fwd_form = tn.forward_form >= 1 && tn.forward_form <= 3 ? tn.forward_form : 0;
+    a.dense_kt1 = tn.dense_one_thread;
+    a.step_form = tn.step_form;
     a.off_logpi = plan->L.off_logpi;
     a.off_A4 = plan->L.off_A4;
     a.off_lo = plan->L.off_lo;
@@ -193,23 +285,45 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
     a.step_cn = plan->bp.step_cn;
     a.off_stepC = plan->L.off_stepC;
     a.off_Arow = plan->L.off_Arow;
+    a.off_tabV = plan->L.off_tabV;
+    a.wave_ok = plan->bp.ok && plan->bp.wave_ok ? 1 : 0;
+    a.wave_npl = plan->bp.wave_npl;
+    a.wave_dk = plan->bp.wave_dk;
+    a.wave_flags = tn.wave_two ? 1 : 0;
     a.win_shift = (plan->bp.ok && plan->bp.lo_affine) ? (plan->bp.lo_off & 3) : 0;
     a.win_shift2 = (plan->bp.ok && plan->bp.pair_ok && plan->bp.lo2_affine) ? (plan->bp.lo2_off & 3) : 0;
-    if (const char* e = std::getenv("VIT_WIN_SHIFT")) a.win_shift = a.win_shift2 = std::atoi(e) & 3;   // timing experiments only
+    if (tn.win_shift >= 0) a.win_shift = a.win_shift2 = tn.win_shift & 3;   // every value is functionally correct
 
+    FwdStamp st;
+    st.ws = workspace;
+    st.B = B;
+    st.T = T;
+    st.family = family;
+    st.SD = a.SD;
+    st.col0 = 0;
+    st.mcol = plan->S;
+    st.have_fmax = family == 2 ? 1 : 0;
     hipError_t e;
-    if (algo == VIT_ALGO_BANDED) {
+    if (family == 3) {
+        st.SD = vit::wave_hist_stride(plan->bp.wave_npl);
+        st.col0 = st.SD - plan->S;
+        st.mcol = 0;
+        st.have_fmax = 1;
+        e = vit::launch_wave(a, emis_dtype == VIT_F16, (hipStream_t)stream);
+    } else if (family == 2) {
         e = vit::launch_banded(a, emis_dtype == VIT_F16, (hipStream_t)stream);
-    } else if (requested == VIT_ALGO_AUTO && a.step_ok && vit::step_kernel_instantiated(a.S, a.step_bw, a.step_kb) &&
-               !(a.debug & 16384)) {
+    } else if (algo == VIT_ALGO_AUTO && a.step_ok && vit::step_kernel_instantiated(a.S, a.step_bw, a.step_kb) &&
+               tn.step_form != 2) {
         // dense matrix with step structure (Durrieu): VIT_ALGO_DENSE still means the plain dense kernel
         e = vit::launch_step(a, emis_dtype == VIT_F16, (hipStream_t)stream);
     } else {
-        int ns = B >= 512 ? 2 : 1;   // songs per workgroup share the streamed matrix (measured at S = 361, B = 1024: 1 -> 57, 2 -> 64, 4 -> 48 Mframes/s)
-        if (const char* e = std::getenv("VIT_DENSE_NS")) ns = std::atoi(e);   // timing experiments only
+        // songs per workgroup share the streamed matrix (measured at S = 361, B = 1024: 1 -> 57, 2 -> 64, 4 -> 48 Mframes/s)
+        const int ns = tn.dense_songs > 0 ? tn.dense_songs : (B >= 512 ? 2 : 1);
         e = vit::launch_dense(a, ns, emis_dtype == VIT_F16, (hipStream_t)stream);
     }
-    return e == hipSuccess ? VIT_OK : hip_fail(e);
+    if (e != hipSuccess) return hip_fail(e);
+    stamp_put(plan, st);
+    return VIT_OK;
 }
 
 int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* lengths, void* workspace,
@@ -217,10 +331,12 @@ int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* len
     int rc = check_common(plan, B, T, workspace, workspace_bytes);
     if (rc != VIT_OK) return rc;
     if (!states) return VIT_EINVAL;
-    algo = resolve_algo(plan, algo);
-    if (algo < 0) return algo;
+    (void)algo;   // kept for ABI compatibility: the layout comes from what vit_forward recorded for this workspace
     if (B == 0) return VIT_OK;
-    const WsLayout w = ws_layout(plan->S, B, T);
+    FwdStamp st;
+    if (!stamp_get(plan, workspace, &st) || st.B != B || st.T != T) return VIT_EINVAL;   // no matching vit_forward
+    const Tuning& tn = plan->tune;
+    const WsLayout w = ws_layout(plan, B, T);
     uint8_t* ws = static_cast<uint8_t*>(workspace);
     vit::BtArgs b{};
     b.image = plan->dev_image;
@@ -231,22 +347,24 @@ int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* len
     b.entry = reinterpret_cast<int32_t*>(ws + w.off_entry);
     b.chunks = vit::backtrace_chunks(B, (int)T);
     b.warm = vit::kBtWarm;
-    // test hooks: force the chunking / warm-up so that the verify-and-repair pass is exercised
-    if (const char* e = std::getenv("VIT_BT_CHUNKS")) { int c = std::atoi(e); if (c >= 1 && c <= vit::kBtMaxChunks) b.chunks = c; }
-    if (const char* e = std::getenv("VIT_BT_WARM")) { int g = std::atoi(e); if (g >= 0) b.warm = g; }
+    // test hooks (vit_plan_set_option): force the chunking / warm-up so that the verify-and-repair pass is exercised
+    if (tn.bt_chunks >= 1 && tn.bt_chunks <= vit::kBtMaxChunks) b.chunks = tn.bt_chunks;
+    if (tn.bt_warm >= 0) b.warm = tn.bt_warm;
     b.B = B;
     b.T = (int)T;
     b.S = plan->S;
     b.SP = plan->L.SP;
-    b.SD = hist_stride(plan->S);
+    b.SD = st.SD;
+    b.col0 = st.col0;
+    b.mcol = st.mcol;
     b.W = plan->bp.ok ? plan->bp.W : 0;
     b.banded = plan->bp.ok ? 1 : 0;
     b.n_extras = plan->bp.ok ? plan->bp.n_extras : 0;
     b.n_dense = plan->bp.ok ? plan->bp.n_dense : 0;
     for (int k = 0; k < vit::kMaxExtras; ++k) b.extras[k] = plan->bp.extras[k];
     b.c0 = plan->bp.c0;
-    b.have_fmax = algo == VIT_ALGO_BANDED ? 1 : 0;
-    if (const char* dbg = std::getenv("VIT_DEBUG_FLAGS")) b.debug = std::atoi(dbg);  // timing experiments only
+    b.have_fmax = st.have_fmax;
+    b.bt_form = tn.backtrace_form;
     b.lo_affine = plan->bp.lo_affine ? 1 : 0;
     b.lo_off = plan->bp.lo_off;
     for (int d = 0; d < vit::kMaxDenseRows; ++d) b.dense_rows[d] = d < plan->bp.n_dense ? plan->bp.dense_rows[d] : -1;
@@ -267,6 +385,7 @@ int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* len
     b.off_denseA = plan->L.off_denseA;
     b.off_Arow = plan->L.off_Arow;
     b.off_rowc = plan->L.off_rowc;
+    if (st.family == 3 && !(b.banded && b.n_dense == 0)) return VIT_EINVAL;   // (cannot happen: wave_ok implies both)
     hipError_t e = vit::launch_backtrace(b, (hipStream_t)stream);
     return e == hipSuccess ? VIT_OK : hip_fail(e);
 }

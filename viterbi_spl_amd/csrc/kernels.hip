@@ -667,7 +667,11 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
     constexpr bool GEN = NXT < 0;
     constexpr int NXL = GEN ? kMaxExtras : NXT;            // extra columns the loops are unrolled for
     const int nx = GEN ? a.n_extras : NXT, nd = GEN ? a.n_dense : 0;
+#ifdef VIT_TIMING_HOOKS
     const int dbg = DBG ? a.debug : 0;
+#else
+    constexpr int dbg = 0;          // the ablation / probe hooks exist only in VIT_TIMING_HOOKS builds (scripts/)
+#endif
 
     // ---------------- per-role setup
     const bool is_target = wv < NWT;
@@ -878,9 +882,9 @@ __global__ void __launch_bounds__((NWT + (DW ? 3 : 2)) * 64) banded_forward_kern
         const float n = (float)(Tb - 1);
         o[0] = (float)ph0 / n; o[1] = (float)ph1 / n; o[2] = (float)ph2 / n; o[3] = (float)ph3 / n;
     }
-    if ((dbg & 48) && tid == 0 && a.loglik) {  // timing experiments only: cycles (16) or 100 MHz ticks (32) per frame
+    if ((dbg & 48) && tid == 0) {  // timing experiments only: cycles (16) or 100 MHz ticks (32) per frame -> scratch slot 63
         const unsigned long long d = (dbg & 16) ? __builtin_amdgcn_s_memtime() - clk0 : __builtin_amdgcn_s_memrealtime() - rt0;
-        a.loglik[song] = (float)d / (float)(Tb > 1 ? Tb - 1 : 1);
+        a.fmax[(size_t)song * 64 + 63] = (float)d / (float)(Tb > 1 ? Tb - 1 : 1);
     }
 }
 
@@ -1070,7 +1074,11 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
         e_slot = load_e<ET>(E + (size_t)tn * S + jld);
         __syncthreads();
     };
+#ifdef VIT_TIMING_HOOKS
     const bool probe = (a.debug & 48) != 0;
+#else
+    constexpr bool probe = false;   // cycle probe: VIT_TIMING_HOOKS builds only; it writes the per-song scratch, never an output
+#endif
     const unsigned long long clk0 = probe ? __builtin_amdgcn_s_memtime() : 0ull;
     const unsigned long long rt0 = probe ? __builtin_amdgcn_s_memrealtime() : 0ull;
     int t = 1;
@@ -1084,9 +1092,9 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
 
     const int fb = (Tb - 1) & 1;                                          // buffer holding delta_{Tb-1}
     terminal_argmax(tvalid ? dls[4 + sh + fb * BUF + j] : -INFINITY, j, tvalid, tot, NWT, a.last_state, a.loglik, song);
-    if (probe && tid == 0 && a.loglik) {  // timing experiments only: cycles (16) or 100 MHz ticks (32) per frame
+    if (probe && tid == 0) {  // timing experiments only: cycles (16) or 100 MHz ticks (32) per frame -> scratch slot 63
         const unsigned long long d = (a.debug & 16) ? __builtin_amdgcn_s_memtime() - clk0 : __builtin_amdgcn_s_memrealtime() - rt0;
-        a.loglik[song] = (float)d / (float)(Tb > 1 ? Tb - 1 : 1);
+        a.fmax[(size_t)song * 64 + 63] = (float)d / (float)(Tb > 1 ? Tb - 1 : 1);
     }
 }
 
@@ -1249,7 +1257,11 @@ __global__ void __launch_bounds__(NPW * 64) banded_floor_pair_forward_kernel(Fwd
         e_slot = f32x2{load_e<ET>(erow + jl0), load_e<ET>(erow + jl1)};
         __syncthreads();
     };
+#ifdef VIT_TIMING_HOOKS
     const bool probe = (a.debug & 48) != 0;
+#else
+    constexpr bool probe = false;   // cycle probe: VIT_TIMING_HOOKS builds only; it writes the per-song scratch, never an output
+#endif
     const unsigned long long clk0 = probe ? __builtin_amdgcn_s_memtime() : 0ull;
     const unsigned long long rt0 = probe ? __builtin_amdgcn_s_memrealtime() : 0ull;
     int t = 1;
@@ -1279,9 +1291,9 @@ __global__ void __launch_bounds__(NPW * 64) banded_floor_pair_forward_kernel(Fwd
             if (a.loglik) a.loglik[song] = acc.v;
         }
     }
-    if (probe && tid == 0 && a.loglik) {  // timing experiments only: cycles (16) or 100 MHz ticks (32) per frame
+    if (probe && tid == 0) {  // timing experiments only: cycles (16) or 100 MHz ticks (32) per frame -> scratch slot 63
         const unsigned long long d = (a.debug & 16) ? __builtin_amdgcn_s_memtime() - clk0 : __builtin_amdgcn_s_memrealtime() - rt0;
-        a.loglik[song] = (float)d / (float)(Tb > 1 ? Tb - 1 : 1);
+        a.fmax[(size_t)song * 64 + 63] = (float)d / (float)(Tb > 1 ? Tb - 1 : 1);
     }
 }
 
@@ -1360,7 +1372,7 @@ __global__ void __launch_bounds__(512) banded_backtrace_kernel(BtArgs a) {
         isw[k] = c < W;
         cand[k] = c < W + nx;
         const int xs = (c >= W && c < W + nx) ? a.extras[(c - W) & (kMaxExtras - 1)] : 0;
-        pb[k] = c == CB ? S : (isw[k] ? c : xs);                             // row entry read (window candidates: + lo)
+        pb[k] = c == CB ? a.mcol : a.col0 + (isw[k] ? c : xs);               // row entry read (window candidates: + lo)
         tb[k] = c < WX1 ? c : WX1 - 1;                                       // entry of the target's table row
         const int nwin = W - 64 * k;
         wmask[k] = nwin >= 64 ? ~0ull : (nwin <= 0 ? 0ull : ((1ull << nwin) - 1ull));
@@ -1372,7 +1384,7 @@ __global__ void __launch_bounds__(512) banded_backtrace_kernel(BtArgs a) {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         const int i = e * 64 + lane;
-        ic[e] = i < SD ? i : SD - 1;
+        ic[e] = i < S ? a.col0 + i : a.col0;
         inS[e] = i < S;
         bool x = i >= S;
 #pragma unroll
@@ -1452,7 +1464,7 @@ __global__ void __launch_bounds__(512) banded_backtrace_kernel(BtArgs a) {
                         }
                         unsigned long long mx = mk & ~wmask[k];              // extra-column candidates: arbitrary indices
                         while (mx) {
-                            const unsigned c = __builtin_amdgcn_readlane(pb[k], __builtin_ctzll(mx));
+                            const unsigned c = __builtin_amdgcn_readlane(pb[k], __builtin_ctzll(mx)) - a.col0;   // column -> state
                             best = c < best ? c : best;
                             mx &= mx - 1;
                         }
@@ -1513,7 +1525,7 @@ __global__ void __launch_bounds__(512) banded_backtrace_kernel(BtArgs a) {
             cur = __builtin_amdgcn_readfirstlane(a.last_state[song]);
         } else {
             // guess: lowest-index argmax of delta row top+1
-            const float* g = hist + (size_t)(top + 1) * SD;
+            const float* g = hist + (size_t)(top + 1) * SD + a.col0;
             float d[EPL];
             float m = -INFINITY;
 #pragma unroll
@@ -1660,7 +1672,7 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
         const int oldv = (MODE == 1 && lane < rows) ? states[first + lane] : -1;   // see banded_backtrace_kernel
         int rstop = -1;
         for (int r = rows - 1; r >= 0; --r) {
-            const float* row = tile + r * SD;   // delta_t, t = first + r; decides the state at frame t
+            const float* row = tile + r * SD + a.col0;   // delta_t, t = first + r; decides the state at frame t
             const int jj = __builtin_amdgcn_readfirstlane(cur);  // path state at frame t+1 (wave-uniform)
             int lo = 0;
             int kd = -3;                         // -3 unstructured plan, -1 banded row, >= 0 dense row
@@ -1683,7 +1695,7 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
                 float v = -INFINITY;
                 if (lane < WX) v = row[src] + tabX[jj * WXS + lane];
                 const float m = wave_max_all(v);
-                const float mf = row[S] + rowcL[jj];  // pad column S = max_i delta_t[i] (non-extra): fl(. + c_jj) bounds every row-constant candidate
+                const float mf = tile[r * SD + a.mcol] + rowcL[jj];  // column mcol >= max_i delta_t[i] over the row-constant sources: fl(. + c_jj) bounds every row-constant candidate
                 if (mf < m) {                    // no row-constant candidate can tie or win
                     const unsigned long long mk = __ballot(v == m);
                     unsigned idx = 0x7fffffffu;
@@ -1807,7 +1819,7 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
             cur = __builtin_amdgcn_readfirstlane(a.last_state[song]);
         } else {
             // guess: lowest-index argmax of delta row top+1
-            const float* g = hist + (size_t)(top + 1) * SD;
+            const float* g = hist + (size_t)(top + 1) * SD + a.col0;
             float d[EPL];
             float m = -INFINITY;
 #pragma unroll
@@ -1888,7 +1900,7 @@ hipError_t launch_step(const FwdArgs& a, bool f16, hipStream_t st) {
     if (!step_kernel_instantiated(a.S, a.step_bw, a.step_kb)) return hipErrorInvalidConfiguration;
     constexpr int VLEN = NWV * 64 + 2 * (KB * BW + BW);
     const size_t lds = sizeof(float) * (2 * KB * VLEN + 2 * (NWV * 64 + 64) + 2 * 16) + sizeof(VI) * 16;
-    if (!(a.debug & 32768)) {   // four targets per lane (32768 selects the one-target form for A/B)
+    if (a.step_form != 1) {     // four targets per lane (step_form 1 selects the one-target form for A/B)
         constexpr int VL4 = 768 + 2 * (KB * BW + BW);
         const size_t lds4 = sizeof(float) * (2 * KB * VL4 + 2 * (768 + 64) + 2 * 4 + 4) + sizeof(VI) * 16;
         if (f16)
@@ -1907,7 +1919,7 @@ hipError_t launch_step(const FwdArgs& a, bool f16, hipStream_t st) {
 hipError_t launch_dense(const FwdArgs& a, int ns, bool f16, hipStream_t st) {
     while (ns > 1 && a.SP > dense_max_threads(ns)) ns >>= 1;
     // one song per workgroup: two threads per target when the workgroup still fits (S <= 512)
-    if (ns == 1 && 2 * a.SP <= 1024 && !(a.debug & 16384))
+    if (ns == 1 && 2 * a.SP <= 1024 && !a.dense_kt1)
         return f16 ? launch_dense_t<1, __half, 2>(a, st) : launch_dense_t<1, float, 2>(a, st);
     if (f16) {
         if (ns >= 8) return launch_dense_t<8, __half>(a, st);
@@ -1928,9 +1940,9 @@ static hipError_t launch_floor_t(const FwdArgs& a, hipStream_t st) {
     constexpr int PF = 4;   // emission rows in flight (2: 13.2 ms, 4: 11.2 ms, 8: 12.4 ms at B = 128)
     // Up to two songs per CU the one-target-per-lane kernel is (slightly) faster; beyond that the two-targets-per-lane
     // kernel wins because it moves half the window bytes through LDS (B = 512: 14.5 vs 15.5 ms).
-    // VIT_DEBUG_FLAGS 512 / 1024 force one or the other.
+    // FwdArgs::fwd_form 1 / 2 force one or the other.
     if constexpr (W <= 32 && NWT <= 8) {   // (at twelve waves, S = 722, the one-target kernel measured faster at every batch size)
-        const bool pair = a.pair_ok && ((a.B > 256 && !(a.debug & 512)) || (a.debug & 1024));
+        const bool pair = a.pair_ok && ((a.B > 256 && a.fwd_form != 1) || a.fwd_form == 2);
         if (pair) {
             constexpr int NPW = (NWT + 1) / 2;
             constexpr int NWMP = (NPW + 3) / 4 * 4;
@@ -1962,8 +1974,10 @@ static hipError_t launch_scan_t(const FwdArgs& a, hipStream_t st) {
     // otherwise lengthen the suffix wave, the critical one).
     if (a.n_dense > 0 && a.B <= 256)
         hipLaunchKernelGGL((banded_forward_kernel<W, NWT, true, false, -1, ET>), dim3((int)a.B), dim3((NWT + 3) * 64), lds, st, a);
-    else if (a.debug & ~2048)
+#ifdef VIT_TIMING_HOOKS
+    else if (a.debug)
         hipLaunchKernelGGL((banded_forward_kernel<W, NWT, false, true, -1, ET>), dim3((int)a.B), dim3((NWT + 2) * 64), lds, st, a);
+#endif
     else if (W == 32 && a.n_dense == 0 && a.n_extras == 1)   // the reference's matrices: band + unvoiced column
         hipLaunchKernelGGL((banded_forward_kernel<W, NWT, false, false, (W == 32 ? 1 : -1), ET>), dim3((int)a.B), dim3((NWT + 2) * 64), lds, st, a);
     else if (W == 32 && a.n_dense == 0 && a.n_extras == 0)
@@ -1975,10 +1989,9 @@ static hipError_t launch_scan_t(const FwdArgs& a, hipStream_t st) {
 
 template <int W, int NWT, typename ET>
 static hipError_t launch_banded_t(const FwdArgs& a, hipStream_t st) {
-    // VIT_DEBUG_FLAGS: 48 cycle probes, 512 / 1024 choose between the floor kernels, 2048 only selects the generic
-    // back-trace; anything else (4096: "scan form", the ablation bits) goes to the general kernel
-    const bool floor_ok = a.floor_ok && a.S < NWT * 64 && !(a.debug & ~(48 | 512 | 1024 | 2048)) &&
-                          !((a.debug & 512) && (a.debug & 1024));
+    // fwd_form 3 forces the general (scan) kernel; so do the ablation bits of a VIT_TIMING_HOOKS build (48 = cycle probes
+    // exist in the floor kernels as well)
+    const bool floor_ok = a.floor_ok && a.S < NWT * 64 && a.fwd_form != 3 && !(a.debug & ~48);
     if constexpr (floor_form_instantiated(W, NWT)) {
         if (floor_ok) return launch_floor_t<W, NWT, ET>(a, st);
     }
@@ -2040,7 +2053,7 @@ template <int NWT>
 static hipError_t launch_bt_t(BtArgs a, hipStream_t st) {
     // lean kernel: banded plan, no dense rows, frame maxima stored by the forward pass
     if constexpr (NWT <= 12) {
-        if (a.banded && a.have_fmax && a.n_dense == 0 && a.W <= 128 && !(a.debug & 2048)) {
+        if (a.banded && a.have_fmax && a.n_dense == 0 && a.W <= 128 && a.bt_form != 1) {
             const int kc = (a.W + kMaxExtras + 1 + 63) / 64;
             const size_t tile = sizeof(f32x4) * kBtVec * 64, lo_tab = sizeof(int32_t) * a.SP;
             const size_t table = sizeof(float) * (size_t)a.SP * (a.W + kMaxExtras + 1);

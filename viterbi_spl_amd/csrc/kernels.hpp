@@ -45,7 +45,10 @@ struct FwdArgs {
     int n_extras, n_dense;
     int extras[kMaxExtras];
     float c0;
-    int debug;              // timing-only ablation mask (VIT_DEBUG_FLAGS); 0 in production
+    int debug;              // timing-only ablation mask; always 0 unless built with -DVIT_TIMING_HOOKS
+    int fwd_form;           // banded forward form: 0 by batch size | 1 one target per lane | 2 two targets per lane | 3 scan
+    int dense_kt1;          // dense kernel: one thread per target even where two fit
+    int step_form;          // step kernel: 1 = one target per lane
     size_t off_logpi, off_A4, off_lo, off_kind, off_tabA, off_extraA, off_denseA, off_rowc, off_lo2, off_tabP;
     int pair_ok;            // the plan proved pair windows: use the two-targets-per-lane kernel
     int floor_ok;           // the plan proved the one-maximum form (banded_floor_forward_kernel)
@@ -53,6 +56,9 @@ struct FwdArgs {
     float step_cn;          // logA_T[j][S-1] for every voiced target j
     size_t off_stepC, off_Arow;
     int win_shift2;         // the same for the pair windows of banded_floor_pair_forward_kernel
+    size_t off_tabV;        // wave form (wave.hip)
+    int wave_ok, wave_npl, wave_dk;
+    int wave_flags;         // bit 0: force the two-waves-per-SIMD instantiation
     int win_shift;          // 0..3: delta is stored shifted by this many floats in LDS so that the window starts of a
                             // 16-lane group are 16-byte aligned in the SAME copy order (bank-conflict-free b128 reads)
 };
@@ -66,10 +72,11 @@ struct BtArgs {
     int32_t* entry;         // [B,chunks] state each chunk assumed at its upper boundary
     int64_t B;
     int T, S, SP, SD, W, K;
+    int col0, mcol;         // history row layout: state i in column col0 + i, the frame maximum in column mcol
     int chunks, warm;       // time-parallel back-trace: chunks per song, warm-up frames
     int banded;             // 1: row structure (window / c0 / extras / dense rows) proven by the plan
     int have_fmax;          // the forward pass was a banded kernel (it fills pad column S of the history rows)
-    int debug;              // timing-only ablation mask (VIT_DEBUG_FLAGS); 0 in production
+    int bt_form;            // 0 auto | 1 generic (lazy) kernel
     int lo_affine, lo_off;  // lo[j] == clamp(j - lo_off, 0, S - W)
     int dense_rows[kMaxDenseRows];
     int n_extras, n_dense;
@@ -83,6 +90,9 @@ struct BtArgs {
 hipError_t launch_dense(const FwdArgs& a, int songs_per_group, bool f16, hipStream_t st);
 hipError_t launch_step(const FwdArgs& a, bool f16, hipStream_t st);
 hipError_t launch_banded(const FwdArgs& a, bool f16, hipStream_t st);
+hipError_t launch_wave(const FwdArgs& a, bool f16, hipStream_t st);   // wave.hip: one song per wavefront
+// history layout of the wave form: row stride 64*npl floats, state i in column 64*npl - S + i, the frame maximum in column 0
+constexpr int wave_hist_stride(int npl) { return 64 * npl; }
 hipError_t launch_backtrace(BtArgs a, hipStream_t st);
 hipError_t launch_voicing_map(const int32_t* states, int64_t n, int32_t n_bins, uint8_t* voiced, int32_t* bins,
                               hipStream_t st);

@@ -153,6 +153,21 @@ BandedPlan analyze_banded(const float* A, int S) {
         }
         bp.floor_ok = ok;
     }
+    // "wave" form: the frame maximum over ALL sources needs the extra-column entries to dominate the row constant as
+    // well; the half-width bounds how many neighbouring lanes a lane must see
+    {
+        bool ok = bp.floor_ok;
+        for (int j = 0; j < S && ok; ++j)
+            for (int k = 0; k < bp.n_extras && ok; ++k)
+                if (!(A[(size_t)j * S + bp.extras[k]] >= bp.rowc[j])) ok = false;
+        bp.floor_all_ok = ok;
+        int d = 0;
+        for (int j = 0; j < S; ++j) d = std::max(d, std::max(j - lo[j], hi[j] - j));
+        bp.wave_d = d;
+        bp.wave_npl = (S + 63) / 64;
+        bp.wave_dk = wave_table_d(bp.wave_npl, d);
+        bp.wave_ok = ok && bp.n_dense == 0 && bp.n_extras <= kWaveMaxExtras && bp.wave_dk > 0 && S < 64 * bp.wave_npl;
+    }
     bp.ok = true;
     return bp;
 }
@@ -222,6 +237,8 @@ ImageLayout make_layout(int S, const BandedPlan& bp) {
     L.off_tabP = off;   off = align256(off + sizeof(float) * (size_t)std::max(L.W, 1) * L.SP);
     L.off_tabX = off;   off = align256(off + sizeof(float) * (size_t)(std::max(L.W, 1) + kMaxExtras + 1) * L.SP);
     L.off_stepC = off;  off = align256(off + sizeof(float) * (size_t)(kMaxStepBands + 1) * L.SP);
+    L.off_tabV = off;
+    if (bp.ok && bp.wave_ok) off = align256(off + sizeof(float) * (size_t)bp.wave_npl * wave_pairs(bp.wave_dk) * 2 * 64);
     L.bytes = off;
     return L;
 }
@@ -277,6 +294,25 @@ void fill_image(const float* A, const float* log_pi, const BandedPlan& bp, const
             for (int k = 0; k < bp.n_extras; ++k) row[L.W + k] = A[(size_t)j * S + bp.extras[k]];
             row[L.W + kMaxExtras] = bp.rowc[j];
         }
+    }
+    if (bp.wave_ok) {   // weights in the order wave_forward_kernel loads them: [own state k][pair m][half h][lane]
+        const int npl = bp.wave_npl, dk = bp.wave_dk, H = wave_halo(npl, dk), NPM = wave_pairs(dk);
+        float* tv = reinterpret_cast<float*>(image + L.off_tabV);
+        for (int k = 0; k < npl; ++k)
+            for (int m = 0; m < NPM; ++m)
+                for (int h = 0; h < 2; ++h)
+                    for (int l = 0; l < 64; ++l) {
+                        // right-aligned slots: slot q holds state q - o, o = 64*npl - S (wave.hip)
+                        const int o = 64 * npl - S;
+                        const int j = npl * l + k - o;
+                        const int i = npl * (l - H) + wave_p0e(npl, dk, k) + 2 * m + h - o;
+                        // always the true matrix entry: positions outside the exception span are the row constant,
+                        // a candidate the dense recursion forms as well; idle targets (j < 0) get -inf so that their
+                        // delta stays -inf; so do sources outside [0, S): whatever a shift delivers there, the
+                        // candidate is -inf
+                        const float v = (j >= 0 && i >= 0 && i < S) ? A[(size_t)j * S + i] : ninf;
+                        tv[(((size_t)k * NPM + m) * 2 + h) * 64 + l] = v;
+                    }
     }
     if (bp.pair_ok) {
         int32_t* lo2 = reinterpret_cast<int32_t*>(image + L.off_lo2);

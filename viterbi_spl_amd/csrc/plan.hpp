@@ -57,7 +57,27 @@ struct BandedPlan {
     int step_bw = 0, step_kb = 0;
     std::vector<float> stepC;   // [(kMaxStepBands+1)][SP], rows > step_kb unused, -inf for i >= n
     float step_cn = 0.f;
+
+    // "Wave" form (wave_forward_kernel: one song per wavefront, no LDS, no barrier).  Lane l owns the wave_npl =
+    // ceil(S/64) contiguous states wave_npl*l ..; every exception span lies within wave_d sources of its target
+    // (|i - j| <= wave_d), so a lane needs delta only from the lanes within ceil(wave_d / wave_npl) of itself.
+    bool floor_all_ok = false;  // floor_ok, and every extra-column entry of a banded row is >= that row's constant too:
+                                // then the frame maximum M may be taken over ALL sources (a dominated candidate more)
+    bool wave_ok = false;       // floor_all_ok, no dense rows, <= kWaveMaxExtras extra columns, an instantiated geometry
+    int wave_npl = 0;
+    int wave_d = 0;             // proven half-width
+    int wave_dk = 0;            // half-width the kernel (and tabV) is instantiated for (>= wave_d)
 };
+
+constexpr int kWaveMaxExtras = 2;
+// half-width the wave kernel is instantiated for, given the states per lane and the proven half-width (0: none)
+constexpr int wave_table_d(int npl, int d) { return (npl == 6 && d <= 14) ? 14 : 0; }
+constexpr int wave_pairs(int dk) { return dk + 1; }   // packed source pairs per target: 2*dk + 1 sources, even-aligned
+constexpr int wave_halo(int npl, int dk) { return (dk + npl - 1) / npl; }   // lanes a lane looks at on each side
+// A lane's neighbourhood is the npl * (2*halo + 1) sources of lanes l-halo .. l+halo, position p <-> source
+// npl * (l - halo) + p.  Own state k evaluates the even-aligned positions p0e .. p0e + 2*(dk+1) - 1, which cover
+// its sources j - dk .. j + dk; pair m, half h sits at p0e + 2m + h.
+constexpr int wave_p0e(int npl, int dk, int k) { return (k + npl * wave_halo(npl, dk) - dk) & ~1; }
 
 constexpr int kMaxStepBands = 15;
 // Fills the step_* fields of bp (bp.SP must be set: call after analyze_banded).
@@ -83,6 +103,7 @@ struct ImageLayout {
     size_t off_tabP = 0;     // float [W][SP]       tabP[w][j] = logA_T[j][lo2[j/2] + w]
     size_t off_tabX = 0;     // float [SP][W+5]     per target: W window entries, 4 extra-column entries, row constant (back-trace)
     size_t off_stepC = 0;    // float [16][SP]      step-structure band values per source (step_ok)
+    size_t off_tabV = 0;     // float [npl][dk+1][2][64]  wave form: weights of lane l, own state k, source pair m, half h
     size_t bytes = 0;
 };
 

@@ -40,6 +40,11 @@ void vph_offsets(const vph_plan* p, long long* off) {
     off[4] = p->L.off_tabA; off[5] = p->L.off_extraA; off[6] = p->L.off_denseA; off[7] = p->L.bytes;
     off[8] = p->L.off_Arow; off[9] = p->L.off_rowc; off[10] = p->L.off_lo2; off[11] = p->L.off_tabP;
 }
+// wave form: w[0..5] = wave_ok, npl, proven half-width, instantiated half-width, floor_all_ok, offset of tabV
+void vph_wave(const vph_plan* p, long long* w) {
+    w[0] = p->bp.wave_ok; w[1] = p->bp.wave_npl; w[2] = p->bp.wave_d; w[3] = p->bp.wave_dk;
+    w[4] = p->bp.floor_all_ok; w[5] = (long long)p->L.off_tabV;
+}
 void vph_image(const vph_plan* p, unsigned char* out) { std::memcpy(out, p->image.data(), p->image.size()); }
 
 }  // extern "C"

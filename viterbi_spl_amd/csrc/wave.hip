@@ -1,0 +1,358 @@
+// wave.hip -- "wave" form of the banded forward pass: ONE SONG PER WAVEFRONT (gfx950).
+//
+// The workgroup kernels of kernels.hip advance a song one frame per LDS round trip and barrier: ~840 cycles per
+// frame whatever the arithmetic, which is what a small batch needs (latency) and what a large batch does not
+// (throughput: four songs per CU still leave the VALU ~60 % idle).  Here a song never leaves one wavefront:
+//
+//   * lane l owns the NPL = ceil(S/64) CONTIGUOUS states NPL*l .. NPL*l + NPL-1; delta lives in registers;
+//   * the plan proved that every exception span lies within D sources of its target, so a lane needs delta only from
+//     the H = ceil(D/NPL) lanes on either side: 2*H wave-wide DPP shifts of its NPL registers (wave_shr:1 / wave_shl:1,
+//     lanes beyond the wave edge read -inf) -- no LDS, no barrier, no other wave;
+//   * own state k evaluates the 2*D+1 sources j-D .. j+D as D+1 even-aligned source pairs: one v_pk_add_f32 and one
+//     v_max3_f32 per pair, weights register-resident (the true matrix entries: positions outside a row's exception span
+//     carry the row constant, a candidate the dense recursion forms as well);
+//   * everything else is the floor-max identity of banded_floor_forward_kernel with M taken over ALL sources
+//     (plan.floor_all_ok: extra-column entries dominate the row constant too, so an extra column inside M only adds a
+//     dominated candidate):  m_j = max( window candidates, fl(M + c_j), fl(delta_x + logA_T[j][x]) for extra columns x ).
+//
+// Every value compared is one the dense recursion forms, so delta is bit-identical (CPU replay: tests/plan_replay.py
+// replay_wave).  Per frame and wave ~245 VALU instructions and nothing to wait for but the emission prefetch; songs
+// of different lengths simply finish at different times.  The history row (delta_t, and M_t in pad column S) is what
+// the back-trace kernels of kernels.hip read -- same workspace layout as the other banded forward kernels.
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "kernels.hpp"
+
+namespace vit {
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// element-aligned vector views: a lane's NPL columns start on a 4-byte (f32) / 2-byte (f16) boundary only
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+typedef _Float16 f16x2_u __attribute__((ext_vector_type(2), aligned(2)));
+typedef _Float16 f16x4_u __attribute__((ext_vector_type(4), aligned(2)));
+
+constexpr int kBigI = 0x7fffffff;
+
+__device__ __forceinline__ int song_length_of(const int64_t* lengths, int song, int T) {
+    if (!lengths) return T;
+    long long v = lengths[song];
+    v = v < 1 ? 1 : v;
+    return v > T ? T : (int)v;
+}
+
+// Wave-wide shifts by one lane.  bound_ctrl: the lane without a source reads 0 -- any finite value would do: the
+// sources that lane stands for do not exist (state < 0 or >= S) and their window weights are -inf (plan.cpp), so the
+// candidate is -inf whatever the shift delivers.  (A fill value would cost a v_mov per shift.)
+__device__ __forceinline__ float dpp_shr1(float x) {   // lane l <- x[l-1]
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_shl1(float x) {   // lane l <- x[l+1]
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130, 0xf, 0xf, true));
+}
+// max over the wave, wave-uniform result (six v_max_f32 with a DPP operand + v_readlane; see kernels.hip wave_scan_max)
+__device__ __forceinline__ float wave_max(float x) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(x));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+
+
+template <int NPL, typename ET>
+struct RowIO;
+
+// float32 emissions: NPL consecutive columns as 16- and 8-byte pieces
+template <int NPL>
+struct RowIO<NPL, float> {
+    static __device__ __forceinline__ void load(const float* __restrict__ p, float (&e)[NPL]) {
+        int k = 0;
+#pragma unroll
+        for (; k + 3 < NPL; k += 4) { const f32x4_u v = *reinterpret_cast<const f32x4_u*>(p + k); e[k] = v.x; e[k + 1] = v.y; e[k + 2] = v.z; e[k + 3] = v.w; }
+#pragma unroll
+        for (; k + 1 < NPL; k += 2) { const f32x2_u v = *reinterpret_cast<const f32x2_u*>(p + k); e[k] = v.x; e[k + 1] = v.y; }
+        if (k < NPL) e[k] = p[k];
+    }
+    static __device__ __forceinline__ float load1(const float* __restrict__ p) { return *p; }
+};
+template <int NPL>
+struct RowIO<NPL, __half> {
+    static __device__ __forceinline__ void load(const __half* __restrict__ ph, float (&e)[NPL]) {
+        const _Float16* p = reinterpret_cast<const _Float16*>(ph);
+        int k = 0;
+#pragma unroll
+        for (; k + 3 < NPL; k += 4) { const f16x4_u v = *reinterpret_cast<const f16x4_u*>(p + k); e[k] = (float)v.x; e[k + 1] = (float)v.y; e[k + 2] = (float)v.z; e[k + 3] = (float)v.w; }
+#pragma unroll
+        for (; k + 1 < NPL; k += 2) { const f16x2_u v = *reinterpret_cast<const f16x2_u*>(p + k); e[k] = (float)v.x; e[k + 1] = (float)v.y; }
+        if (k < NPL) e[k] = (float)p[k];
+    }
+    static __device__ __forceinline__ float load1(const __half* __restrict__ p) { return __half2float(*p); }
+};
+
+template <int NPL>
+__device__ __forceinline__ void store_row(float* __restrict__ p, const float (&d)[NPL]) {
+    int k = 0;
+#pragma unroll
+    for (; k + 3 < NPL; k += 4) { f32x4_u v; v.x = d[k]; v.y = d[k + 1]; v.z = d[k + 2]; v.w = d[k + 3]; *reinterpret_cast<f32x4_u*>(p + k) = v; }
+#pragma unroll
+    for (; k + 1 < NPL; k += 2) { f32x2_u v; v.x = d[k]; v.y = d[k + 1]; *reinterpret_cast<f32x2_u*>(p + k) = v; }
+    if (k < NPL) p[k] = d[k];
+}
+
+}  // namespace
+
+// NPL states per lane, D window half-width, NX extra columns, PF emission rows in flight, WPS minimum waves per SIMD the
+// register budget must allow.
+//
+// Lane <-> state mapping, RIGHT-aligned: slot q = NPL*lane + k (k = 0 .. NPL-1) holds state q - o with o = 64*NPL - S,
+// so lane 63 ends exactly at state S-1 and the o leading slots are idle (weights -inf: their delta stays -inf).  With
+// that, a lane's NPL emission columns are one unconditional vector load at E_row + NPL*lane - o -- for the leading
+// lanes that reaches back into the previous row of the SAME tensor (rows >= 1 only: row 0 is loaded element-wise), never
+// out of bounds -- and the history row is stored in slot order: row stride 64*NPL floats, state i in column o + i, and
+// M_t = max_i delta_t[i] in column 0 (an idle slot).  No branch surrounds a memory instruction, so the in-order vmcnt
+// of the emission prefetch is exact.  The back-trace is told the column offset and the column of M (BtArgs::col0, mcol).
+template <int NPL, int D, int NX, int PF, int WPS, typename ET>
+__global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
+    constexpr int H = wave_halo(NPL, D);
+    constexpr int NG = 2 * H + 1;              // lane groups of the neighbourhood
+    constexpr int NPM = wave_pairs(D);
+    constexpr int SDW = 64 * NPL;              // history row stride of this form
+    static_assert(NPL <= 8 && NPL % 2 == 0 && NX <= kWaveMaxExtras && PF >= 1, "geometry (source pairs never straddle two lanes)");
+    const int S = a.S, T = a.T;
+    const int lane = threadIdx.x & 63;
+    const int song = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (song >= a.B) return;                   // whole waves only; there is no barrier in this kernel
+    const int Tb = song_length_of(a.lengths, song, T);
+    const ET* __restrict__ E = reinterpret_cast<const ET*>(a.logE) + (size_t)song * T * S;
+    float* __restrict__ hist = a.hist + (size_t)song * T * SDW;
+
+    // ---------------- per-lane constants
+    const int o = SDW - S;                                 // idle leading slots (>= 1)
+    const int j0 = NPL * lane - o;                         // state of slot 0 of this lane (negative: idle)
+    f32x2 aw[NPL][NPM];
+    {
+        const float* __restrict__ tv = reinterpret_cast<const float*>(a.image + a.off_tabV);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k)
+#pragma unroll
+            for (int m = 0; m < NPM; ++m) {
+                aw[k][m].x = tv[(((size_t)k * NPM + m) * 2 + 0) * 64 + lane];
+                aw[k][m].y = tv[(((size_t)k * NPM + m) * 2 + 1) * 64 + lane];
+            }
+    }
+    float cj[NPL];
+    float xa[NX > 0 ? NX : 1][NPL];
+    int xl[NX > 0 ? NX : 1];                               // lane that owns extra column x
+    bool xs[NX > 0 ? NX : 1][NPL];                         // this lane's slot k holds extra column x
+    {
+        const float* __restrict__ rc = reinterpret_cast<const float*>(a.image + a.off_rowc);
+        const float* __restrict__ xaT = reinterpret_cast<const float*>(a.image + a.off_extraA);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const int j = j0 + k;
+            cj[k] = j >= 0 ? rc[j] : -INFINITY;
+#pragma unroll
+            for (int x = 0; x < NX; ++x) xa[x][k] = j >= 0 ? xaT[(size_t)x * a.SP + j] : -INFINITY;
+        }
+#pragma unroll
+        for (int x = 0; x < NX; ++x) {
+            xl[x] = (a.extras[x] + o) / NPL;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) xs[x][k] = j0 + k == a.extras[x];
+        }
+    }
+    // emission columns of this lane in rows >= 1 (see above); a single-row tensor (T == 1) never uses them
+    const long ecol = T > 1 ? (long)j0 : (long)(j0 < 0 ? 0 : j0);
+    const int row_min = T > 1 ? 1 : 0;
+    auto load_row = [&](int row, float (&e)[NPL]) {
+        row = row < row_min ? row_min : row;
+        RowIO<NPL, ET>::load(E + (size_t)row * S + ecol, e);
+    };
+    // history row t in slot order; lane 0's first slot (always idle) carries M_t
+    auto store_hist = [&](const int t, const float (&d)[NPL], const float M) {
+        float v[NPL];
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) v[k] = d[k];
+        v[0] = lane == 0 ? M : v[0];
+        store_row<NPL>(hist + (size_t)t * SDW + NPL * lane, v);
+    };
+
+    // ---------------- frame 0
+    float d[NPL];
+    {
+        const float* __restrict__ lpi = reinterpret_cast<const float*>(a.image + a.off_logpi);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const int j = j0 + k;
+            d[k] = j >= 0 ? lpi[j] + RowIO<NPL, ET>::load1(E + j) : -INFINITY;
+        }
+    }
+    auto frame_max = [&](const float (&v)[NPL]) -> float {
+        float loc = v[0];
+#pragma unroll
+        for (int k = 1; k < NPL; ++k) loc = fmaxf(loc, v[k]);
+        return wave_max(loc);
+    };
+    float M = frame_max(d);
+    store_hist(0, d, M);
+
+    float er[PF][NPL];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) load_row(1 + q < Tb ? 1 + q : Tb - 1, er[q]);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k)
+#pragma unroll
+        for (int m = 0; m < NPM; ++m) asm volatile("" ::"v"(aw[k][m]));
+
+    auto frame = [&](const int t, float (&e)[NPL]) {
+        // ---- extra columns: delta of state x, wave-uniform
+        float xd[NX > 0 ? NX : 1];
+#pragma unroll
+        for (int x = 0; x < NX; ++x) {
+            float v = d[0];
+#pragma unroll
+            for (int k = 1; k < NPL; ++k) v = xs[x][k] ? d[k] : v;   // per-lane masks: one v_cndmask each
+            xd[x] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), xl[x]));
+        }
+        // ---- neighbourhood: group g holds delta of lane l - H + g
+        float nb[NG][NPL];
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) nb[H][k] = d[k];
+#pragma unroll
+        for (int s = 1; s <= H; ++s)
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                nb[H - s][k] = dpp_shr1(nb[H - s + 1][k]);
+                nb[H + s][k] = dpp_shl1(nb[H + s - 1][k]);
+            }
+        auto NB = [&](const int p) -> float { return p < NG * NPL ? nb[p / NPL][p % NPL] : -INFINITY; };
+        // ---- window candidates: D+1 packed adds and max3 per own state, walked source pair by source pair from the
+        //      lane's own group outwards (the order the shifts deliver them) so that consecutive instructions belong to
+        //      different states: independent chains, no wait state between a packed add and the max3 that reads it
+        float acc[NPL];
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) acc[k] = -INFINITY;
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const int g = gi == 0 ? H : (gi & 1 ? H - (gi + 1) / 2 : H + gi / 2);
+#pragma unroll
+            for (int pp = (g * NPL) / 2; 2 * pp < (g + 1) * NPL + 1; ++pp) {
+                const int p = 2 * pp;
+                if (p / NPL != g && !(NPL % 2 && (p + 1) / NPL == g && p / NPL == g - 1 && false)) continue;
+                f32x2 c[NPL];
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) {
+                    const int p0 = wave_p0e(NPL, D, k);
+                    if (p >= p0 && p < p0 + 2 * NPM) c[k] = f32x2{NB(p), NB(p + 1)} + aw[k][(p - p0) / 2];
+                }
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) {
+                    const int p0 = wave_p0e(NPL, D, k);
+                    if (p >= p0 && p < p0 + 2 * NPM) acc[k] = fmaxf(fmaxf(acc[k], c[k].x), c[k].y);
+                }
+            }
+        }
+        // ---- floor term, extra columns, emission
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            float m = fmaxf(acc[k], M + cj[k]);
+#pragma unroll
+            for (int x = 0; x < NX; ++x) m = fmaxf(m, xd[x] + xa[x][k]);
+            d[k] = m + e[k];
+        }
+        M = frame_max(d);
+        store_hist(t, d, M);
+        load_row(t + PF < Tb ? t + PF : Tb - 1, e);
+    };
+    int t = 1;
+    for (; t + PF - 1 < Tb; t += PF) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) frame(t + q, er[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < PF - 1; ++q)
+        if (t + q < Tb) frame(t + q, er[q]);
+
+    // ---------------- terminal state: lowest-index argmax of delta_{Tb-1}
+    {
+        float bv = -INFINITY;
+        int bi = kBigI;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k)
+            if (j0 + k >= 0 && (d[k] > bv || bi == kBigI)) { bv = d[k]; bi = j0 + k; }   // first state of the lane, then strictly greater
+        // lanes ascend with the state index: an ordered (value, index) scan keeps the first maximum
+#define VIT_WSTEP(CTRL, MASK)                                                                                      \
+    {                                                                                                              \
+        const float sv = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-INFINITY), __float_as_int(bv), CTRL, MASK, 0xf, false)); \
+        const int si = __builtin_amdgcn_update_dpp(kBigI, bi, CTRL, MASK, 0xf, false);                               \
+        const bool keep_earlier = !(bv > sv);   /* kernels.hip op_fwd: the later piece wins only if strictly greater */ \
+        bv = keep_earlier ? sv : bv;                                                                               \
+        bi = keep_earlier ? si : bi;                                                                               \
+    }
+        VIT_WSTEP(0x111, 0xf)
+        VIT_WSTEP(0x112, 0xf)
+        VIT_WSTEP(0x114, 0xf)
+        VIT_WSTEP(0x118, 0xf)
+        VIT_WSTEP(0x142, 0xa)
+        VIT_WSTEP(0x143, 0xc)
+#undef VIT_WSTEP
+        if (lane == 63) {
+            a.last_state[song] = bi == kBigI ? 0 : bi;
+            if (a.loglik) a.loglik[song] = bv;
+        }
+    }
+}
+
+template <int NPL, int D, int NX, typename ET>
+static hipError_t launch_wave_x(const FwdArgs& a, hipStream_t st) {
+    const int grid = (int)((a.B + 3) / 4);
+    // up to one wave per SIMD on the chip (1024 songs) the deeper prefetch of the 512-register form is free
+    if (a.B <= 1024 && !(a.wave_flags & 1))
+        hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, 4, 1, ET>), dim3(grid), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, 2, 2, ET>), dim3(grid), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+template <int NPL, int D, typename ET>
+static hipError_t launch_wave_n(const FwdArgs& a, hipStream_t st) {
+    switch (a.n_extras) {
+        case 0: return launch_wave_x<NPL, D, 0, ET>(a, st);
+        case 1: return launch_wave_x<NPL, D, 1, ET>(a, st);
+        case 2: return launch_wave_x<NPL, D, 2, ET>(a, st);
+        default: return hipErrorInvalidConfiguration;
+    }
+}
+
+template <typename ET>
+static hipError_t launch_wave_e(const FwdArgs& a, hipStream_t st) {
+    if (a.wave_dk != 14) return hipErrorInvalidConfiguration;
+    switch (a.wave_npl) {
+        case 6: return launch_wave_n<6, 14, ET>(a, st);
+        default: return hipErrorInvalidConfiguration;
+    }
+}
+
+hipError_t launch_wave(const FwdArgs& a, bool f16, hipStream_t st) {
+    if (!a.wave_ok) return hipErrorInvalidConfiguration;
+    return f16 ? launch_wave_e<__half>(a, st) : launch_wave_e<float>(a, st);
+}
+
+}  // namespace vit

@@ -61,7 +61,7 @@ class ViterbiDecoder:
         _lib.check(lib.vit_plan_query(self._plan, ctypes.byref(info)), "vit_plan_query")
         self.info = {
             "S": int(info.S), "banded_ok": bool(info.banded_ok), "n_extras": int(info.n_extras),
-            "n_dense_rows": int(info.reserved[0]), "floor_ok": bool(info.reserved[1]), "lo_affine": bool(info.reserved[2] & 1), "pair_ok": bool(info.reserved[2] & 2), "step_ok": bool(info.reserved[2] & 4), "max_window": int(info.max_window),
+            "n_dense_rows": int(info.reserved[0]), "floor_ok": bool(info.reserved[1]), "lo_affine": bool(info.reserved[2] & 1), "pair_ok": bool(info.reserved[2] & 2), "step_ok": bool(info.reserved[2] & 4), "wave_ok": bool(info.reserved[2] & 8), "max_window": int(info.max_window),
             "group_window": int(info.group_window), "row_constant": float(info.consts[0]),
             "extras": [int(info.extras[k]) for k in range(int(info.n_extras))],
         }
@@ -82,6 +82,11 @@ class ViterbiDecoder:
                 self._plan = ctypes.c_void_p()
         except Exception:
             pass
+
+    def set_option(self, key: str, value: int) -> None:
+        """Kernel-selection override (``vit_plan_set_option``; keys in include/viterbi_hip.h).  Every setting decodes the
+        same bits; ``set_option("reset", 0)`` restores the defaults."""
+        _lib.check(_lib.load().vit_plan_set_option(self._plan, key.encode(), int(value)), f"vit_plan_set_option({key})")
 
     # ------------------------------------------------------------------ workspace
     def workspace_bytes(self, B: int, T: int) -> int:
