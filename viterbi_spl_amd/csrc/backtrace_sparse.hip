@@ -1,0 +1,330 @@
+// backtrace_sparse.hip -- exact, time-parallel back-trace that fetches only the part of the delta history it uses.
+//
+// banded_backtrace_kernel (kernels.hip) stages whole history rows through LDS: 1456 B per frame to use ~33 floats, and it
+// is HBM-bound doing so (5.5 TB/s; 21 % of a step at B = 1024).  The path moves slowly -- a band transition moves it by
+// at most the band half-width, and in music it moves by a bin or two per frame -- so this kernel fetches, for a tile of
+// K frames, only
+//   * the SPAN: NS consecutive columns around the window of the current path state (NS = 64: the W-wide window plus a
+//     guard on either side), the same columns for every row of the tile, and
+//   * the row's auxiliary values: the frame maximum (column mcol) and delta of the extra columns,
+// i.e. 3-5 cache lines of a row's 12.  Per frame t (descending) the decision is the one banded_backtrace_kernel takes:
+// candidates fl(delta_t[i] + logA_T[j][i]) over the window and the extra columns of the path state j at t+1, wave max,
+// and if fl(M_t + c_j) < max no row-constant candidate can tie or win: lowest matching index.  Otherwise (rare: e.g.
+// a voiced -> unvoiced switch, whose best source can be any voiced state) the whole row is evaluated straight from
+// global memory -- exact either way.  When the path leaves the span (a jump through the floor or an extra column, or
+// accumulated drift) the tile is dropped and re-fetched around the new state, starting at the frame that missed.
+// Chunking, speculative warm-up and the verify-and-repair pass are those of banded_backtrace_kernel.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "kernels.hpp"
+
+namespace vit {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kSpK = 16;            // rows per tile
+constexpr int kSpNS = 64;           // span columns per row (multiple of 4)
+constexpr int kSpAux = 8;           // auxiliary floats per row: [0] frame maximum, [1 + k] extra column k
+constexpr int kSpRS = kSpNS + kSpAux;   // floats per tile row
+constexpr int kSpVec = kSpK * kSpNS / 4 / 64;   // float4 per lane per tile
+
+__device__ __forceinline__ int sp_song_length(const int64_t* lengths, int song, int T) {
+    if (!lengths) return T;
+    long long v = lengths[song];
+    v = v < 1 ? 1 : v;
+    return v > T ? T : (int)v;
+}
+__device__ __forceinline__ float sp_wave_max(float x) {   // kernels.hip wave_max_all
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(x));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+
+}  // namespace
+
+// NWT: 64 * NWT >= S (sources per lane in the full evaluation).  AFF: window start affine in the target.
+// MODE 0: speculative pass, one wave per (song, chunk).  MODE 1: verify-and-repair pass, one wave per song.
+template <int NWT, bool AFF, int MODE>
+__global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int EPL = NWT;
+    const int S = a.S, SP = a.SP, SD = a.SD, T = a.T, W = a.W;
+    const int nx = a.n_extras;
+    const int WX1 = W + kMaxExtras + 1;    // candidate-table row: window, extras, row constant
+    const int CB = W + kMaxExtras;         // candidate index of the bound (<= 63: checked by the launcher)
+    const int nwaves = blockDim.x >> 6;
+    float* tiles = reinterpret_cast<float*>(smem);                          // [nwaves][kSpK * kSpRS]
+    int32_t* loL = reinterpret_cast<int32_t*>(tiles + nwaves * kSpK * kSpRS);   // [SP]
+    float* tabX = reinterpret_cast<float*>(loL + SP);                       // [SP][WX1]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {
+        const int32_t* gl = reinterpret_cast<const int32_t*>(a.image + a.off_lo);
+        const float* __restrict__ gtab = reinterpret_cast<const float*>(a.image + a.off_tabX);
+        const int nthr = blockDim.x;
+        for (int k = tid; k < SP; k += nthr) loL[k] = gl[k];
+        for (int k = tid; k < SP * WX1; k += nthr) tabX[k] = gtab[k];
+    }
+    __syncthreads();
+
+    const int C = a.chunks;
+    const int gw = blockIdx.x * nwaves + wv;
+    const int song = MODE == 0 ? gw / C : gw;
+    const int chunk = MODE == 0 ? gw % C : 0;
+    if (song >= a.B) return;
+    const int Tb = sp_song_length(a.lengths, song, T);
+    int32_t* __restrict__ states = a.states + (size_t)song * T;
+    const float* __restrict__ hist = a.hist + (size_t)song * T * SD;
+    float* tile = tiles + wv * kSpK * kSpRS;
+
+    // ---- per-lane constants: lane l < W window candidate l, lanes W .. W+nx-1 the extra columns, lane CB the bound
+    const bool isw = lane < W;
+    const bool isx = lane >= W && lane < W + nx;
+    const bool cand = lane < W + nx;
+    const int xs = isx ? a.extras[(lane - W) & (kMaxExtras - 1)] : 0;      // state of the extra-column candidate
+    const int auxi = lane == CB ? 0 : 1 + ((lane - W) & (kMaxExtras - 1));  // aux entry read by a non-window lane
+    const int tb = lane < WX1 ? lane : WX1 - 1;
+    const unsigned long long wmask = W >= 64 ? ~0ull : ((1ull << W) - 1ull);
+    // aux loads: entry e of row r by lane r * 8 + e (two halves of eight rows)
+    const int aux_e = lane & 7;
+    const int aux_col = aux_e == 0 ? a.mcol : (aux_e <= nx ? a.col0 + a.extras[(aux_e - 1) & (kMaxExtras - 1)] : a.mcol);
+    bool inS[EPL], xcol[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int i = e * 64 + lane;
+        inS[e] = i < S;
+        bool x = i >= S;
+#pragma unroll
+        for (int k = 0; k < kMaxExtras; ++k) x |= (k < nx && i == a.extras[k]);
+        xcol[e] = x;
+    }
+    const int lo_max = S - W;
+    const int c0_max = (SD - kSpNS) & ~3;
+
+    // chase(top, bottom, cur, write): decide the states of frames top .. bottom (descending) from the delta rows
+    // top .. bottom, starting from state `cur` at frame top+1.
+    auto chase = [&](int top, const int bottom, int cur, const bool write) -> int {
+        while (top >= bottom) {
+            cur = __builtin_amdgcn_readfirstlane(cur);
+            const int first = top - kSpK + 1 > bottom ? top - kSpK + 1 : bottom;
+            const int rows = top - first + 1;
+            // ---- fetch the tile: span columns [c0, c0 + NS) of rows first .. top, centred on the window of `cur`
+            int lo_c;
+            if (AFF) { lo_c = cur - a.lo_off; lo_c = lo_c < 0 ? 0 : (lo_c > lo_max ? lo_max : lo_c); }
+            else lo_c = __builtin_amdgcn_readfirstlane(loL[cur]);
+            int c0 = (a.col0 + lo_c - (kSpNS - W) / 2) & ~3;
+            c0 = c0 < 0 ? 0 : (c0 > c0_max ? c0_max : c0);
+            {
+                f32x4 stage[kSpVec];
+                float auxv[2];
+#pragma unroll
+                for (int v = 0; v < kSpVec; ++v) {
+                    const int idx = lane + 64 * v;
+                    int r = idx / (kSpNS / 4);
+                    const int q = idx % (kSpNS / 4);
+                    r = r < rows ? r : rows - 1;
+                    stage[v] = *reinterpret_cast<const f32x4*>(hist + (size_t)(first + r) * SD + c0 + 4 * q);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    int r = (lane >> 3) + 8 * h;
+                    r = r < rows ? r : rows - 1;
+                    auxv[h] = hist[(size_t)(first + r) * SD + aux_col];
+                }
+#pragma unroll
+                for (int v = 0; v < kSpVec; ++v) {
+                    const int idx = lane + 64 * v;
+                    *reinterpret_cast<f32x4*>(tile + (idx / (kSpNS / 4)) * kSpRS + 4 * (idx % (kSpNS / 4))) = stage[v];
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) tile[((lane >> 3) + 8 * h) * kSpRS + kSpNS + aux_e] = auxv[h];
+            }
+            int outv = 0;
+            const int oldv = (MODE == 1 && lane < rows) ? states[first + lane] : -1;
+            int rstop = -1;          // MODE 1: row at which the new path met the stored one
+            int rmiss = -1;          // row whose window left the span: the tile is re-fetched from there
+            for (int r = __builtin_amdgcn_readfirstlane(rows - 1); r >= 0; --r) {
+                cur = __builtin_amdgcn_readfirstlane(cur);
+                int lo;
+                if (AFF) { lo = cur - a.lo_off; lo = lo < 0 ? 0 : (lo > lo_max ? lo_max : lo); }
+                else lo = __builtin_amdgcn_readfirstlane(loL[cur]);
+                const int wlo = a.col0 + lo - c0;                       // window start inside the span
+                if (wlo < 0 || wlo + W > kSpNS) { rmiss = r; break; }
+                const float* trow = tile + r * kSpRS;
+                const float dv = trow[isw ? wlo + lane : kSpNS + auxi];
+                const float av = tabX[cur * WX1 + tb];
+                float v = dv + av;
+                const float mf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), CB));   // fl(M_t + c_cur)
+                const float cj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(av), CB));
+                v = cand ? v : -INFINITY;
+                const float m = sp_wave_max(v);
+                auto lowest_candidate = [&](const float mm) -> unsigned {
+                    unsigned best = 0x7fffffffu;
+                    const unsigned long long mk = __ballot(v == mm && cand);
+                    if (mk & wmask) best = lo + __builtin_ctzll(mk & wmask);     // window candidates ascend with the source
+                    unsigned long long mx = mk & ~wmask;                        // extra columns: arbitrary indices
+                    while (mx) {
+                        const unsigned c = __builtin_amdgcn_readlane(xs, __builtin_ctzll(mx));
+                        best = c < best ? c : best;
+                        mx &= mx - 1;
+                    }
+                    return best;
+                };
+                unsigned idx = 0x7fffffffu;
+                if (mf < m) {
+                    idx = lowest_candidate(m);
+                } else {
+                    // ---- full evaluation, straight from the history row in global memory: every source outside the
+                    //      window / extra columns contributes fl(delta_t[i] + c_cur)
+                    const float* __restrict__ grow = hist + (size_t)(first + r) * SD + a.col0;
+                    float vf[EPL];
+                    float m2 = -INFINITY;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) {
+                        const int i = e * 64 + lane;
+                        const float d = inS[e] ? grow[i] : -INFINITY;
+                        const bool excl = xcol[e] || (unsigned)(i - lo) < (unsigned)W;
+                        vf[e] = excl ? -INFINITY : d + cj;
+                        m2 = fmaxf(m2, vf[e]);
+                    }
+                    const float mm = fmaxf(m, sp_wave_max(m2));
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) {
+                        const unsigned long long mk = __ballot(vf[e] == mm && inS[e]);
+                        if (mk) { const unsigned c = e * 64 + __builtin_ctzll(mk); idx = c < idx ? c : idx; }
+                    }
+                    const unsigned c = lowest_candidate(mm);
+                    idx = c < idx ? c : idx;
+                    if (idx == 0x7fffffffu) idx = 0;        // an all -inf frame resolves to index 0 like np.argmax
+                }
+                cur = (int)idx;
+                outv = lane == r ? cur : outv;
+                if (MODE == 1 && cur == __builtin_amdgcn_readlane(oldv, r)) { rstop = r; break; }
+            }
+            const int rkeep = rstop > rmiss ? rstop : rmiss;     // rows above rkeep were decided in this pass
+            if (write && lane < rows && lane > rkeep) states[first + lane] = outv;
+            if (MODE == 1 && rstop >= 0) return __builtin_amdgcn_readfirstlane(states[bottom]);   // the stored path continues unchanged
+            top = rmiss >= 0 ? first + rmiss : first - 1;
+        }
+        return cur;
+    };
+
+    const int Lf = Tb - 1;
+    if (MODE == 0) {
+        const int lo_c = (int)((long long)Lf * chunk / C), hi_c = (int)((long long)Lf * (chunk + 1) / C);
+        if (chunk == C - 1) {
+            for (int t = Tb + lane; t < T; t += 64) states[t] = -1;
+            if (lane == 0) states[Tb - 1] = a.last_state[song];
+        }
+        int top = hi_c - 1 + a.warm;
+        int cur;
+        if (chunk == C - 1 || top >= Lf - 1) {
+            top = Lf - 1;
+            cur = __builtin_amdgcn_readfirstlane(a.last_state[song]);
+        } else {
+            // guess: lowest-index argmax of delta row top+1
+            const float* g = hist + (size_t)(top + 1) * SD + a.col0;
+            float d[EPL];
+            float m = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                d[e] = inS[e] ? g[e * 64 + lane] : -INFINITY;
+                m = fmaxf(m, d[e]);
+            }
+            m = sp_wave_max(m);
+            unsigned idx = 0x7fffffffu;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const unsigned long long mk = __ballot(d[e] == m && inS[e]);
+                if (mk) { const unsigned c = e * 64 + __builtin_ctzll(mk); idx = c < idx ? c : idx; }
+            }
+            cur = idx == 0x7fffffffu ? 0 : (int)idx;
+        }
+        if (hi_c <= lo_c) {                       // empty chunk (very short song)
+            if (lane == 0) a.entry[(size_t)song * C + chunk] = cur;
+            return;
+        }
+        cur = chase(top, hi_c, cur, false);       // warm-up: frames top .. hi_c, nothing written
+        if (lane == 0) a.entry[(size_t)song * C + chunk] = cur;   // state this chunk assumed at frame hi_c
+        chase(hi_c - 1, lo_c, cur, true);
+    } else {
+        int truth = -1;                           // verified state at frame hi_c of the chunk being checked
+        for (int c = C - 2; c >= 0; --c) {
+            const int lo_c = (int)((long long)Lf * c / C), hi_c = (int)((long long)Lf * (c + 1) / C);
+            if (truth < 0) truth = __builtin_amdgcn_readfirstlane(states[hi_c]);
+            const int assumed = __builtin_amdgcn_readfirstlane(a.entry[(size_t)song * C + c]);
+            if (hi_c > lo_c && assumed != truth) {
+                truth = chase(hi_c - 1, lo_c, truth, true);   // re-chase from the true state; ends at frame lo_c
+            } else {
+                truth = -1;                       // chunk c stands: its frame lo_c is already in `states`
+            }
+        }
+    }
+}
+
+size_t sparse_backtrace_lds(const BtArgs& a, int nwaves) {
+    return sizeof(float) * ((size_t)nwaves * kSpK * kSpRS + (size_t)a.SP * (a.W + kMaxExtras + 1)) + sizeof(int32_t) * a.SP;
+}
+
+// The sparse kernel takes banded plans without dense rows whose forward pass left the frame maximum in the history,
+// with every candidate on one lane and the span inside a row.
+bool sparse_backtrace_applies(const BtArgs& a) {
+    return a.banded && a.have_fmax && a.n_dense == 0 && a.W + kMaxExtras + 1 <= 64 && a.W + 8 <= kSpNS && a.SD >= kSpNS &&
+           a.SD % 4 == 0 && (a.S + 63) / 64 <= 12 && sparse_backtrace_lds(a, 4) + 1024 <= 160 * 1024;
+}
+
+template <int NWT, bool AFF>
+static hipError_t launch_sparse_t(const BtArgs& a, hipStream_t st) {
+    int nw = 16;
+    while (nw > 4 && sparse_backtrace_lds(a, nw) + 1024 > 160 * 1024) nw >>= 1;
+    const size_t lds = sparse_backtrace_lds(a, nw);
+    const long long waves0 = (long long)a.B * a.chunks;
+    hipLaunchKernelGGL((sparse_backtrace_kernel<NWT, AFF, 0>), dim3((int)((waves0 + nw - 1) / nw)), dim3(nw * 64), lds, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || a.chunks <= 1) return e;
+    hipLaunchKernelGGL((sparse_backtrace_kernel<NWT, AFF, 1>), dim3((int)((a.B + nw - 1) / nw)), dim3(nw * 64), lds, st, a);
+    return hipGetLastError();
+}
+
+template <int NWT>
+static hipError_t launch_sparse_a(const BtArgs& a, hipStream_t st) {
+    return a.lo_affine ? launch_sparse_t<NWT, true>(a, st) : launch_sparse_t<NWT, false>(a, st);
+}
+
+hipError_t launch_backtrace_sparse(const BtArgs& a, hipStream_t st) {
+    const int nwt = (a.S + 63) / 64;
+    if (nwt <= 2) return launch_sparse_a<2>(a, st);
+    if (nwt <= 4) return launch_sparse_a<4>(a, st);
+    if (nwt <= 6) return launch_sparse_a<6>(a, st);
+    if (nwt <= 8) return launch_sparse_a<8>(a, st);
+    return launch_sparse_a<12>(a, st);
+}
+
+// more, shorter chunks than the whole-row kernels: the sparse kernel hides its fetch latency with waves, not with a
+// second tile in registers (sixteen waves per CU at 1024 songs and up)
+int sparse_backtrace_chunks(int64_t B, int T) {
+    long long c = (4 * 1024 + B - 1) / (B > 0 ? B : 1);
+    const long long cmax = T / (8 * kBtWarm) > 1 ? T / (8 * kBtWarm) : 1;
+    c = c > cmax ? cmax : c;
+    c = c > kBtMaxChunks ? kBtMaxChunks : c;
+    return c < 1 ? 1 : (int)c;
+}
+
+}  // namespace vit

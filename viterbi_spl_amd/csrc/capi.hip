@@ -345,11 +345,6 @@ int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* len
     b.lengths = lengths;
     b.states = states;
     b.entry = reinterpret_cast<int32_t*>(ws + w.off_entry);
-    b.chunks = vit::backtrace_chunks(B, (int)T);
-    b.warm = vit::kBtWarm;
-    // test hooks (vit_plan_set_option): force the chunking / warm-up so that the verify-and-repair pass is exercised
-    if (tn.bt_chunks >= 1 && tn.bt_chunks <= vit::kBtMaxChunks) b.chunks = tn.bt_chunks;
-    if (tn.bt_warm >= 0) b.warm = tn.bt_warm;
     b.B = B;
     b.T = (int)T;
     b.S = plan->S;
@@ -386,6 +381,12 @@ int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* len
     b.off_Arow = plan->L.off_Arow;
     b.off_rowc = plan->L.off_rowc;
     if (st.family == 3 && !(b.banded && b.n_dense == 0)) return VIT_EINVAL;   // (cannot happen: wave_ok implies both)
+    b.chunks = (b.bt_form == 0 && vit::sparse_backtrace_applies(b)) ? vit::sparse_backtrace_chunks(B, (int)T)
+                                                                     : vit::backtrace_chunks(B, (int)T);
+    b.warm = vit::kBtWarm;
+    // test hooks (vit_plan_set_option): force the chunking / warm-up so that the verify-and-repair pass is exercised
+    if (tn.bt_chunks >= 1 && tn.bt_chunks <= vit::kBtMaxChunks) b.chunks = tn.bt_chunks;
+    if (tn.bt_warm >= 0) b.warm = tn.bt_warm;
     hipError_t e = vit::launch_backtrace(b, (hipStream_t)stream);
     return e == hipSuccess ? VIT_OK : hip_fail(e);
 }

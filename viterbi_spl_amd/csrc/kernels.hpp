@@ -76,7 +76,7 @@ struct BtArgs {
     int chunks, warm;       // time-parallel back-trace: chunks per song, warm-up frames
     int banded;             // 1: row structure (window / c0 / extras / dense rows) proven by the plan
     int have_fmax;          // the forward pass was a banded kernel (it fills pad column S of the history rows)
-    int bt_form;            // 0 auto | 1 generic (lazy) kernel
+    int bt_form;            // 0 auto (sparse fetch where it applies) | 1 generic (lazy) kernel | 2 whole-row kernels
     int lo_affine, lo_off;  // lo[j] == clamp(j - lo_off, 0, S - W)
     int dense_rows[kMaxDenseRows];
     int n_extras, n_dense;
@@ -94,6 +94,10 @@ hipError_t launch_wave(const FwdArgs& a, bool f16, hipStream_t st);   // wave.hi
 // history layout of the wave form: row stride 64*npl floats, state i in column 64*npl - S + i, the frame maximum in column 0
 constexpr int wave_hist_stride(int npl) { return 64 * npl; }
 hipError_t launch_backtrace(BtArgs a, hipStream_t st);
+// backtrace_sparse.hip: fetches only the span of each history row around the path (banded plans, candidates on one lane)
+bool sparse_backtrace_applies(const BtArgs& a);
+hipError_t launch_backtrace_sparse(const BtArgs& a, hipStream_t st);
+int sparse_backtrace_chunks(int64_t B, int T);
 hipError_t launch_voicing_map(const int32_t* states, int64_t n, int32_t n_bins, uint8_t* voiced, int32_t* bins,
                               hipStream_t st);
 hipError_t launch_scan_selftest(const float* vals, int n_waves, int mode, float* out_v, int32_t* out_i,
