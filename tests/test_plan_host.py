@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import viterbi_oracle as vo
-from tests.plan_replay import HostPlan, replay_banded, replay_dense_image
+from tests.plan_replay import HostPlan, replay_banded, replay_dense_image, replay_wave
 from viterbi_spl_amd import synth
 
 
@@ -194,3 +194,71 @@ def test_step_structure_of_the_durrieu_matrix(golden):
         m[n] = np.max((delta + A[n]).astype(np.float32))
         delta = (m + E[t]).astype(np.float32)
     assert delta.tobytes() == rdelta.tobytes()
+
+
+# ------------------------------------------------------------------ wave form (wave_forward_kernel: one song per wavefront)
+@pytest.mark.parametrize("pname,kind,T,seed", [
+    ("tonet361", "peaks", 90, 1), ("tonet361", "dense", 90, 2), ("tonet361", "ties", 90, 3),
+    ("msnet321", "peaks", 80, 4), ("msnet321", "ties", 80, 5),
+])
+def test_wave_form_replay_is_bit_exact(golden, pname, kind, T, seed):
+    """The reference's matrices qualify for the wave form (every exception span within 14 sources of its target, extra-column
+    entries above the row constant); the packed table tabV + the frame maximum over ALL sources replay bit for bit."""
+    from tests.common import GEN
+    p = golden["params"]
+    A, pi = p[f"{pname}_logA_T"], p[f"{pname}_log_pi"]
+    plan = HostPlan(A, pi)
+    assert plan.wave_ok and plan.floor_all_ok and plan.wave_npl == 6 and plan.wave_dk == 14
+    assert plan.wave_d == {"tonet361": 14, "msnet321": 12}[pname]
+    E = GEN[kind](1, T, A.shape[0], seed=seed)[0].numpy()
+    hist, delta = replay_wave(plan, E)
+    _, _, rdelta = vo.decode_c(A, pi, E, return_delta=True)
+    assert delta.tobytes() == rdelta.tobytes()
+    # the history layout the back-trace reads: state i in column 64*npl - S + i, the frame maximum in column 0
+    o = 64 * plan.wave_npl - plan.S
+    assert hist.shape[1] == 64 * plan.wave_npl and hist[-1, o:].tobytes() == rdelta.tobytes()
+    assert hist[-1, 0] == np.max(rdelta)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_wave_form_on_random_banded_structures(seed):
+    """Six states per lane (S in 321..383), half-widths up to 14, 0-2 extra columns anywhere, coarse value grid (ties),
+    floors that regularly win.  Where the plan offers the wave form its replay must equal the dense oracle; it must
+    not offer it when an extra-column entry lies below a row constant (M over all sources would then be wrong)."""
+    rng = np.random.default_rng(500 + seed)
+    S = int(rng.integers(321, 384))
+    half = int(rng.integers(1, 15))
+    extras = sorted(set(int(x) for x in rng.integers(0, S, int(rng.integers(0, 3)))))
+    floor = -50.0 if seed % 2 else -3.0
+    A = _banded_matrix(S, half, rng, extras, (), floor=floor, quant=2)
+    pi = -(rng.integers(0, 8, S) / 2).astype(np.float32)
+    plan = HostPlan(A, pi)
+    assert plan.ok
+    extras_dominate = all(np.all(A[:, x] >= plan.rowc[:S]) for x in plan.extras)
+    assert plan.floor_all_ok == (plan.floor_ok and extras_dominate)
+    assert plan.wave_ok == (plan.floor_all_ok and plan.n_dense == 0 and plan.wave_d <= 14 and plan.n_extras <= 2)
+    if floor == -50.0:
+        assert plan.wave_ok, (S, half, extras)
+    if plan.wave_ok:
+        E = -(rng.integers(0, 6, (50, S)) / 2).astype(np.float32)
+        _, delta = replay_wave(plan, E)
+        _, _, rdelta = vo.decode_c(A, pi, E, return_delta=True)
+        assert delta.tobytes() == rdelta.tobytes()
+
+
+def test_wave_form_is_refused_when_an_extra_column_is_below_the_row_constant():
+    rng = np.random.default_rng(77)
+    S = 350
+    A = _banded_matrix(S, 6, rng, extras=(S - 1,), floor=-10.0, quant=4)   # band and extra-column entries in [-9.75, 0]
+    assert HostPlan(A, np.zeros(S, np.float32)).wave_ok
+    A[:, S - 1] -= 15.0                                                     # extra-column entries now below the floor
+    plan = HostPlan(A, np.zeros(S, np.float32))
+    assert plan.ok and plan.floor_ok and not plan.floor_all_ok and not plan.wave_ok
+
+
+def test_wave_form_needs_six_states_per_lane_and_narrow_bands():
+    logA_T, log_pi = synth.log_params(synth.tonet_transition(720, 40), synth.floored_prior(721))
+    assert not HostPlan(logA_T, log_pi).wave_ok                      # 12 states per lane, half-width 40: workgroup kernels
+    logA_T, log_pi = synth.log_params(synth.tonet_transition(360, 20), synth.floored_prior(361))
+    p = HostPlan(logA_T, log_pi)
+    assert p.ok and p.wave_d == 20 and not p.wave_ok                 # half-width beyond the instantiated 14

@@ -1726,8 +1726,12 @@ __global__ void __launch_bounds__(kBtWaves * 64) lazy_backtrace_kernel(BtArgs a)
 #pragma unroll
                     for (int e = 0; e < EPL; ++e) {
                         const int i = e * 64 + lane;
-                        const bool excl = isx[e] || (unsigned)(i - lo) < (unsigned)W;
-                        vf[e] = excl ? -INFINITY : d[e] + cjj;
+                        // window sources lo .. lo+63 are the lanes of vw; a wider window (W = 96, 128) continues here with
+                        // its table entries; everything else outside the extra columns carries the row constant
+                        const unsigned wi = (unsigned)(i - lo);
+                        const bool in_vw = wi < (unsigned)(W < 64 ? W : 64);
+                        const float wgt = (wi < (unsigned)W && !in_vw) ? tabX[jj * WXS + (int)wi] : cjj;
+                        vf[e] = (isx[e] || in_vw) ? -INFINITY : d[e] + wgt;
                     }
                     if (WX > 64) {  // extras did not fit beside the window: fold them into the strided part
 #pragma unroll
