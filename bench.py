@@ -1,27 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- Viterbi Mframes/s at S=361, T=30000 on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path over one batch of synthetic songs per GPU:
-forward max-plus recursion + back-trace for [B=128, T=30000, S=361] float32 log-emissions
-already resident in HBM, plus (N > 1) the RCCL gather of the decoded paths on rank 0.
-Per-GPU work is fixed as N grows (weak scaling: 128 songs per GPU = BASELINE configs[2],
-and configs[3] = 1024 songs over 8 GPUs).
+A "step" is one pass of the hot path over one batch of synthetic songs per GPU: forward max-plus recursion +
+back-trace for [B=128, T=30000, S=361] float32 log-emissions already resident in HBM, plus (N > 1) the RCCL gather
+of the decoded paths on rank 0.  Per-GPU work is fixed as N grows (weak scaling: 128 songs per GPU = BASELINE
+configs[2]; configs[3] = 1024 songs over 8 GPUs).
 
-The forward pass and the back-trace of a step run back to back on one HIP stream (overlapping the back-trace of
-step i with the forward pass of step i+1 on a second stream was measured: the HBM-bound back-trace slows the
-latency-bound forward pass from 10.6 to 13.7 ms, a net loss).  Only the gather (N > 1) is overlapped: it is
-launched non-blocking on the communicator's stream after the back-trace of step i and completes under the
-forward pass of step i+1; every batch in flight has its own workspace, path buffer and gather buffer (two
-slots).  The timed region ends with a device synchronisation and the completion of every gather.
-`--serial` waits for each gather before the next step starts.
+Schedule of the timed region: the forward pass of step i runs on one HIP stream, its back-trace on a second one
+(ordered by an event), so the back-trace of step i -- 0.6 ms on the half of the chip the 128 one-song workgroups
+leave idle -- overlaps the forward pass of step i+1; every batch in flight has its own workspace, path buffer and
+gather buffer (two slots).  With N > 1 the gather of step i is launched non-blocking on the communicator's stream
+behind its back-trace.  The region ends with a device synchronisation and the completion of every gather: all K
+steps are complete inside it.  `--serial` runs forward, back-trace and gather of a step back to back on one stream.
+
+Rank 0 prints ONE JSON line (always the last line of stdout).  At N = 1 it also carries, measured in the same process:
+  "sweep"    B = 256 / 512 / 1024 / 2048 at S=361 fp32 (the saturation regime; songs repeat with period 32),
+  "configs4" [256, 30000, 722] fp16 emissions (BASELINE configs[4]): jdc band (d_max 40) and the Durrieu matrix,
+  "cpu_baseline" the oracle (NumPy restatement of the reference's loop, one thread) on a bounded sample of the same
+             songs -- which doubles as a parity check of the GPU result -- and the C restatement on all cores.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
-
-Rank 0 prints ONE JSON line.  The CPU baseline leg (rank 0, N == 1 only) runs the oracle --
-the NumPy restatement of the reference's loop, one thread -- on a bounded sample of the same
-songs and doubles as a parity check of the GPU result.
 """
 from __future__ import annotations
 
@@ -51,25 +51,66 @@ def parse():
     ap.add_argument("--batch", type=int, default=128, help="songs per GPU")
     ap.add_argument("--frames", type=int, default=30000)
     ap.add_argument("--states", type=int, default=361)
-    ap.add_argument("--algo", default="auto", choices=["auto", "dense", "banded"])
+    ap.add_argument("--algo", default="auto", choices=["auto", "dense", "banded", "wave", "group"])
     ap.add_argument("--emissions", default="peaks", choices=["peaks", "dense"])
     ap.add_argument("--transition", default="tonet", choices=["tonet", "dense", "durrieu"])
     ap.add_argument("--f16", action="store_true", help="store emissions as float16")
     ap.add_argument("--dmax", type=int, default=14, help="band half-width of the tonet-recipe transition (tonet 14, jdc 40, imm 56)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the sweep / configs4 blocks")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--serial", action="store_true", help="no overlap between consecutive steps (one stream)")
+    ap.add_argument("--serial", action="store_true", help="one stream: no overlap between consecutive steps")
+    ap.add_argument("--option", action="append", default=[], help="vit_plan_set_option key=value (kernel-selection override)")
     return ap.parse_args()
 
 
-def make_params(args):
-    S = args.states
-    if args.transition == "tonet":
-        return synth.log_params(synth.tonet_transition(S - 1, args.dmax), synth.floored_prior(S))
-    if args.transition == "durrieu":   # imm's own decoder: dense, piecewise constant in 20-bin distance bands, uniform prior
+def make_params(transition, S, dmax):
+    if transition == "tonet":
+        return synth.log_params(synth.tonet_transition(S - 1, dmax), synth.floored_prior(S))
+    if transition == "durrieu":   # imm's own decoder: dense, piecewise constant in 20-bin distance bands, uniform prior
         A = synth.durrieu_transition(S - 1, 20)
         return (np.require(np.log(A).astype(np.float32).T, np.float32, ["C"]), np.log(np.full(S, 1.0 / S)).astype(np.float32))
     return synth.dense_random_log_transition(S, seed=3), synth.dense_random_log_transition(S, seed=4)[0].copy()
+
+
+def forward_kernel_name(dec, algo, B, S):
+    """Name of the forward kernel the library launches for (plan, algo, batch): same rules as capi.hip / kernels.hip."""
+    info = dec.info
+    if algo in ("auto", "banded", "wave", "group") and info["banded_ok"]:
+        nwt = next((w for w in (2, 4, 6, 8, 12) if w * 64 >= S), 0)
+        if algo == "wave" or (algo != "group" and info["wave_ok"] and B >= 704):
+            return "wave_forward_kernel"
+        floor_form = info["floor_ok"] and info["n_dense_rows"] == 0 and S < nwt * 64
+        if not floor_form:
+            return "banded_forward_kernel"
+        pair = info["pair_ok"] and B > 256 and nwt <= 8 and info["group_window"] <= 32
+        return "banded_floor_pair_forward_kernel" if pair else "banded_floor_forward_kernel"
+    if algo == "auto" and info["step_ok"]:
+        return "step4_forward_kernel"
+    return "dense_forward_kernel"
+
+
+def time_serial(dec, E, algo, steps, warmup=1):
+    """forward + back-trace of one batch back to back on the current stream; HIP events around each half."""
+    B, T, _ = E.shape
+    st = torch.empty((B, T), dtype=torch.int32, device=E.device)
+    ll = torch.empty((B,), dtype=torch.float32, device=E.device)
+    for _ in range(warmup):
+        dec.decode_into(E, st, ll, algo=algo)
+    torch.cuda.synchronize()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ev[i][0].record()
+        dec.decode_into(E, st, ll, algo=algo, phase="forward")
+        ev[i][1].record()
+        dec.decode_into(E, st, ll, algo=algo, phase="backtrace")
+        ev[i][2].record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    fwd = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    bt = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    return {"wall_ms_per_step": wall / steps * 1e3, "forward_ms": fwd, "backtrace_ms": bt}, st, ll
 
 
 def cpu_baseline(logA_T, log_pi, E, gpu_states, gpu_loglik, seconds):
@@ -102,6 +143,65 @@ def cpu_baseline(logA_T, log_pi, E, gpu_states, gpu_loglik, seconds):
     return out, out_c
 
 
+def tiled_emissions(gen, B, T, S, seed, dev, dtype, period=32):
+    """[B,T,S] emissions whose songs repeat with `period` (generating 2048 distinct 30000-frame songs would take longer
+    than the measurement; identical songs at different addresses cost the kernels the same)."""
+    base = gen(min(B, period), T, S, seed=seed, device=dev, dtype=dtype)
+    if B <= period:
+        return base
+    return base.repeat((B + period - 1) // period, 1, 1)[:B].contiguous()
+
+
+def oracle_spot_check(logA_T, log_pi, E, states, loglik, songs):
+    from oracle import viterbi_oracle as vo
+    rs, rl = vo.decode_c(logA_T, log_pi, E[songs].float().cpu().numpy())
+    return bool(np.array_equal(states[songs].cpu().numpy(), rs)) and bool(np.array_equal(loglik[songs].cpu().numpy(), rl))
+
+
+def extra_blocks(dev, args):
+    """The saturation sweep and the high-resolution configuration, measured in this process after the headline."""
+    out = {}
+    T = args.frames
+    # ---- sweep: S=361 fp32, tonet matrix, larger batches (same kernels the library picks for those sizes)
+    logA_T, log_pi = make_params("tonet", 361, 14)
+    dec = ViterbiDecoder(logA_T, log_pi, dev)
+    sweep = {}
+    for B in (256, 512, 1024, 2048):
+        E = tiled_emissions(synth.emissions_peaks, B, T, 361, 1234, dev, torch.float32)
+        r, st, ll = time_serial(dec, E, "banded", steps=3)
+        fb = B * T * (361 * 4 + 361 * 2)
+        r.update({"songs": B, "Mframes_per_s": B * T / (r["forward_ms"] + r["backtrace_ms"]) / 1e3,
+                  "forward_kernel": forward_kernel_name(dec, "banded", B, 361),
+                  "forward_hbm_frac": fb / (r["forward_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "whole_path_hbm_frac": B * T * 2172 / ((r["forward_ms"] + r["backtrace_ms"]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "bit_exact_vs_oracle_sample": oracle_spot_check(logA_T, log_pi, E, st, ll, [0, 17, 31])})
+        sweep[f"B{B}"] = r
+        del E, st, ll
+        dec._ws = None
+        torch.cuda.empty_cache()
+    out["sweep"] = {"workload": f"T={T}, S=361, fp32 log-emissions (peaks), tonet transition; songs repeat with period 32; "
+                                "forward + back-trace back to back on one stream, 3 steps", **sweep}
+    del dec
+    # ---- configs[4]: S=722 (721 bins + unvoiced), fp16 emissions, 256 songs
+    c4 = {}
+    for name, tr, dmax in (("jdc_band_dmax40", "tonet", 40), ("durrieu_dense", "durrieu", None)):
+        A, pi = make_params(tr, 722, dmax or 14)
+        dec = ViterbiDecoder(A, pi, dev)
+        E = tiled_emissions(synth.emissions_peaks, 256, T, 722, 1234, dev, torch.float16)
+        r, st, ll = time_serial(dec, E, "auto", steps=2)
+        fb = 256 * T * (722 * 2 + 722 * 2)
+        r.update({"Mframes_per_s": 256 * T / (r["forward_ms"] + r["backtrace_ms"]) / 1e3,
+                  "forward_kernel": forward_kernel_name(dec, "auto", 256, 722),
+                  "forward_hbm_frac": fb / (r["forward_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "bit_exact_vs_oracle_sample": oracle_spot_check(A, pi, E, st, ll, [0, 31])})
+        c4[name] = r
+        del E, st, ll, dec
+        torch.cuda.empty_cache()
+    out["configs4"] = {"workload": f"[256, {T}, 722] fp16 log-emissions (peaks), songs repeat with period 32 (BASELINE configs[4]); "
+                                   "2 steps, one stream", **c4}
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,67 +212,70 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"     # the latter: rehearse the gather path on one GPU
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     B, T, S = args.batch, args.frames, args.states
-    logA_T, log_pi = make_params(args)
+    logA_T, log_pi = make_params(args.transition, S, args.dmax)
     dec = ViterbiDecoder(logA_T, log_pi, dev)
+    for kv in args.option:
+        k, v = kv.split("=")
+        dec.set_option(k, int(v))
     algo = args.algo
-    if algo == "auto":
-        algo = "banded" if dec.info["banded_ok"] else "auto"      # "auto": the step-structured kernel if the plan proves it, else dense
+    if algo == "auto" and dec.info["banded_ok"]:
+        algo = "banded"
     gen = synth.emissions_peaks if args.emissions == "peaks" else synth.emissions_dense
     dt = torch.float16 if args.f16 else torch.float32
     E = gen(B, T, S, seed=1234, device=dev, dtype=dt, first_song=rank * B)
     n_total = B * world
-    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"     # the latter: rehearse the gather path on one GPU
-    NSLOT = 2 if use_dist else 1                   # batches in flight (the gather of step i overlaps step i+1)
+    NSLOT = 1 if (args.serial and not use_dist) else 2     # batches in flight
     for k in range(NSLOT):
-        dec._workspace(B, T, k)                     # allocate before anything is timed
+        dec._workspace(B, T, k)                              # allocate before anything is timed
     states_k = [torch.empty((B, T), dtype=torch.int32, device=dev) for _ in range(NSLOT)]
     loglik_k = [torch.empty((B,), dtype=torch.float32, device=dev) for _ in range(NSLOT)]
-    if use_dist and not dist.is_initialized():
-        dist.init_process_group("nccl", device_id=dev)
     if use_dist and rank == 0:
         out_k = [(torch.empty((world, B, T), dtype=torch.int32, device=dev), torch.empty((world, B), dtype=torch.float32, device=dev))
                  for _ in range(NSLOT)]
     else:
         out_k = [(None, None)] * NSLOT
-    pending = [None] * NSLOT
-    gather_mode = ["async"]
+    pending = [None] * NSLOT        # gather handles per slot
+    bt_done = [None] * NSLOT        # event: back-trace of the batch in this slot finished
+    s_fwd = torch.cuda.Stream(device=dev)
+    s_bt = torch.cuda.Stream(device=dev) if not args.serial else s_fwd
 
-    def step(i, ev=None, overlap_gather=True):
-        """forward(i), back-trace(i) on the current stream; the gather of the paths on the communicator's stream."""
+    def step(i, ev=None):
         k = i % NSLOT
         if pending[k] is not None:                     # gather(i - NSLOT) still reads states_k[k]
             for w in pending[k]:
                 w.wait()
             pending[k] = None
-        if ev is not None:
-            ev[0].record()
-        dec.decode_into(E, states_k[k], loglik_k[k], algo=algo, phase="forward", slot=k)
-        if ev is not None:
-            ev[1].record()
-        dec.decode_into(E, states_k[k], loglik_k[k], algo=algo, phase="backtrace", slot=k)
-        if ev is not None:
-            ev[2].record()
-        if use_dist:
-            if gather_mode[0] == "async":
-                try:
-                    pending[k] = sharded.gather_paths_async(states_k[k], loglik_k[k], out_k[k][0], out_k[k][1], dst=0)
-                except Exception as exc:           # defensive: fall back to the plain blocking gather
-                    if rank == 0:
-                        print(f"bench: non-blocking gather unavailable ({exc!r}); using the blocking gather", file=sys.stderr)
-                    gather_mode[0] = "blocking"
-            if gather_mode[0] == "blocking":
-                sharded.gather_paths(states_k[k], loglik_k[k], n_total, dst=0)
-            elif not overlap_gather:
-                for w in pending[k]:
-                    w.wait()
-                pending[k] = None
-
-    def step_serial(i, ev=None):
-        step(i, ev, overlap_gather=False)
+        with torch.cuda.stream(s_fwd):
+            if bt_done[k] is not None and s_bt is not s_fwd:
+                s_fwd.wait_event(bt_done[k])           # back-trace(i - NSLOT) still reads workspace slot k
+            if ev is not None:
+                ev[0].record()
+            dec.decode_into(E, states_k[k], loglik_k[k], algo=algo, phase="forward", slot=k)
+            if ev is not None:
+                ev[1].record()
+            fwd_done = torch.cuda.Event()
+            fwd_done.record()
+        with torch.cuda.stream(s_bt):
+            if s_bt is not s_fwd:
+                s_bt.wait_event(fwd_done)
+            if ev is not None:
+                ev[2].record()
+            dec.decode_into(E, states_k[k], loglik_k[k], algo=algo, phase="backtrace", slot=k)
+            if ev is not None:
+                ev[3].record()
+            bt_done[k] = torch.cuda.Event()
+            bt_done[k].record()
+            if use_dist:                               # ordered behind the back-trace (current stream), runs on the communicator's stream
+                pending[k] = sharded.gather_paths_async(states_k[k], loglik_k[k], out_k[k][0], out_k[k][1], dst=0)
+                if args.serial:
+                    for w in pending[k]:
+                        w.wait()
+                    pending[k] = None
 
     def drain():
         for k in range(NSLOT):
@@ -182,14 +285,14 @@ def main():
                 pending[k] = None
         torch.cuda.synchronize()
 
-    def timed(step_fn, n, with_events):
-        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)] if with_events else [None] * n
+    def timed(n, with_events):
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n)] if with_events else [None] * n
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(n):
-            step_fn(i, evs[i])
+            step(i, evs[i])
         drain()
         if use_dist:
             dist.barrier()
@@ -200,82 +303,83 @@ def main():
             dt_ = float(tmax.item())
         return dt_, evs
 
-    step_fn = step_serial if args.serial else step
     for k in range(NSLOT):             # prime every slot once (code objects, first touch of the workspaces) whatever --warmup says
-        step_fn(k)
+        step(k)
     drain()
     for i in range(args.warmup):
-        step_fn(i)
+        step(i)
     drain()
-    elapsed, events = timed(step_fn, args.steps, True)
+    elapsed, events = timed(args.steps, True)
     states, loglik = states_k[(args.steps - 1) % NSLOT], loglik_k[(args.steps - 1) % NSLOT]
-
     fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
-    bt_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
+    bt_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in events]))
 
     if rank == 0:
         esize = 2 if args.f16 else 4
         frames_per_launch = B * T
-        fwd_bytes = frames_per_launch * (S * esize + S * 2)          # emission row in, uint16 back-pointer row out
-        bt_bytes = frames_per_launch * (2 + 4)                       # one back-pointer in, one int32 state out
+        bpf = S * esize + S * 2                                          # emission row in, uint16 back-pointer row out
+        fwd_bytes = frames_per_launch * bpf
         value = n_total * T * args.steps / elapsed / 1e6
         achieved = fwd_bytes / (fwd_ms * 1e-3) / 1e9
-        traffic = None
+        fwd_kernel = forward_kernel_name(dec, algo, B, S)
+        traffic = bt_traffic = None
+        traffic_source = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
-        key = f"{algo}_B{B}_T{T}_S{S}_{'f16' if args.f16 else 'f32'}"
-        if os.path.exists(tf):       # PMC measurement of the same command, collected by scripts/pmc_traffic.sh
+        key = f"{fwd_kernel}_B{B}_T{T}_S{S}_{'f16' if args.f16 else 'f32'}"
+        if os.path.exists(tf):       # PMC measurement of the same kernels on the same shapes (scripts/pmc_target.sh), not of this run
             try:
-                traffic = json.load(open(tf)).get(key, {}).get("hbm_bytes_per_launch")
+                rec = json.load(open(tf)).get(key, {})
+                traffic = rec.get("forward_hbm_bytes_per_launch")
+                bt_traffic = rec.get("backtrace_hbm_bytes_per_launch")
+                if traffic is not None:
+                    traffic_source = f"profiles/traffic.json[{key}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernels and shapes ({rec.get('profile', 'r02')}); looked up, not measured in this run"
             except Exception:
                 traffic = None
-        bt_traffic = None
-        if os.path.exists(tf):
-            try:
-                bt_traffic = json.load(open(tf)).get(key, {}).get("backtrace", {}).get("hbm_bytes_per_launch")
-            except Exception:
-                bt_traffic = None
-        SD = (S + 5) // 4 * 4
-        fwd_kernel = "step4_forward_kernel" if (dec.info["step_ok"] and args.algo == "auto") else "dense_forward_kernel"
-        if algo == "banded":   # same rule as launch_banded_t (kernels.hip)
-            nwt = next((w for w in (2, 4, 6, 8, 12) if w * 64 >= S), 0)
-            floor_form = dec.info["floor_ok"] and dec.info["n_dense_rows"] == 0 and S < nwt * 64
-            fwd_kernel = "banded_forward_kernel"
-            if floor_form:
-                fwd_kernel = "banded_floor_pair_forward_kernel" if (dec.info["pair_ok"] and B > 256 and nwt <= 8 and dec.info["group_window"] <= 32) else "banded_floor_forward_kernel"
+        workload = (f"batch of {B} songs per GPU, T={T}, S={S}, {'fp16' if args.f16 else 'fp32'} log-emissions ({args.emissions}), "
+                    f"{args.transition} transition" + (f" (band half-width {args.dmax})" if args.transition == "tonet" else "") +
+                    ", forward + back-trace" + (" + RCCL gather of paths" if use_dist else ""))
+        if (B, T, S, args.f16, args.transition, args.dmax) == (128, 30000, 361, False, "tonet", 14):
+            workload += " = BASELINE configs[2] (configs[3] at 8 GPUs)"
         out = {
             "metric": "Viterbi Mframes/s at S=361 T=30k; achieved HBM GB/s vs peak",
             "value": value, "unit": "Mframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"batch of {B} songs per GPU, T={T}, S={S}, {'fp16' if args.f16 else 'fp32'} log-emissions "
-                                   f"(BASELINE configs[2]; configs[3] at 8 GPUs), forward + back-trace"
-                                   + (" + RCCL gather of paths" if use_dist else ""),
-                       "songs_per_gpu": B, "frames": T, "states": S, "emissions": args.emissions,
+            "config": {"workload": workload, "songs_per_gpu": B, "frames": T, "states": S, "emissions": args.emissions,
+                       "emission_storage": "f16" if args.f16 else "f32",
                        "transition": args.transition, "band_half_width": args.dmax if args.transition == "tonet" else None,
-                       "forward_kernel": algo, "plan": dec.info},
+                       "algo": algo, "forward_kernel": fwd_kernel, "plan": dec.info, "options": args.option},
+            "schedule": ("one stream: forward, back-trace" + (", gather" if use_dist else "") + " of a step back to back") if args.serial else
+                        ("two streams: back-trace of step i overlaps the forward pass of step i+1; two workspace slots" +
+                         ("; non-blocking gather on the communicator's stream" if use_dist else "")),
             "roofline": {"bound": "hbm", "kernel": fwd_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": fwd_bytes, "avg_launch_ms": fwd_ms,
-                         "bytes_per_frame": S * esize + S * 2,
-                         "note": "algorithmic bytes per SURVEY 8d (emission row in + uint16 back-pointer row out); this "
-                                 "implementation stores the float32 delta row instead (lazy back-pointers, DESIGN.md), "
-                                 "and the recursion is fp32-VALU / latency bound, not HBM bound"},
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "algorithmic_bytes_per_launch": fwd_bytes, "avg_launch_ms": fwd_ms, "bytes_per_frame": bpf,
+                         "note": "algorithmic bytes per SURVEY 8d (emission row in + uint16 back-pointer row out); the kernels "
+                                 "store the float32 delta row instead (lazy back-pointers, DESIGN.md 4.0)"},
             "kernels_ms": {"forward": fwd_ms, "backtrace": bt_ms},
-            "gather": (None if not use_dist else ("blocking" if (args.serial or gather_mode[0] == "blocking") else
-                       "non-blocking on the communicator's stream, completes under the next step's forward pass; two path-buffer slots")),
-            "backtrace": {"algorithmic_bytes_per_launch": bt_bytes, "traffic": bt_traffic,
-                          "implementation_bytes_per_frame": SD * 4,
-                          "hbm_gbs_from_traffic": (bt_traffic / (bt_ms * 1e-3) / 1e9) if bt_traffic else None},
-            "whole_path_bytes_per_frame": S * esize + S * 2 + 6,
-            "whole_path_hbm_frac": value * 1e6 * (S * esize + S * 2 + 6) / 1e9 / (HBM_PEAK_GBS * world),
+            "backtrace": {"algorithmic_bytes_per_launch": frames_per_launch * 6, "traffic": bt_traffic},
+            "whole_path_bytes_per_frame": bpf + 6,
+            "whole_path_hbm_frac": value * 1e6 * (bpf + 6) / 1e9 / (HBM_PEAK_GBS * world),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not use_dist:
             torch.cuda.synchronize()
-            cb, cbc = cpu_baseline(logA_T, log_pi, E, states, loglik, args.cpu_seconds)
-            out["cpu_baseline"] = cb
-            out["cpu_baseline_c"] = cbc
-            out["gpu_over_cpu_1core"] = value / cb["value"]
-        print(json.dumps(out))
+            if not args.serial:        # the same steps without the overlap, for the record
+                ser, _, _ = time_serial(dec, E, algo, steps=3)
+                out["serial_schedule"] = {**ser, "Mframes_per_s": B * T / ser["wall_ms_per_step"] / 1e3}
+            if not args.no_cpu_baseline:
+                cb, cbc = cpu_baseline(logA_T, log_pi, E, states, loglik, args.cpu_seconds)
+                out["cpu_baseline"] = cb
+                out["cpu_baseline_c"] = cbc
+                out["gpu_over_cpu_1core"] = value / cb["value"]
+            if not args.no_extras:
+                del E, states_k, loglik_k, states, loglik
+                dec._ws = None
+                dec._ws_slots = {}
+                torch.cuda.empty_cache()
+                out.update(extra_blocks(dev, args))
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -155,6 +155,22 @@ int vit_backtrace(const vit_plan *plan, int64_t B, int64_t T, const int64_t *len
 int vit_voicing_map(const int32_t *states, int64_t n, int32_t n_bins, uint8_t *voiced, int32_t *bins,
                     vit_stream stream);
 
+/* The same map plus the bin -> note lookup the metrics consume (tonet/for_paper.py:2106-2115 est_notes_360_fn, :2207):
+ * notes = note_range[bins], notes_voiced = voiced ? notes : 0.  note_range: device, [n_bins] float32.  Any of the four
+ * outputs may be NULL. */
+int vit_voicing_notes(const int32_t *states, int64_t n, int32_t n_bins, const float *note_range, uint8_t *voiced,
+                      int32_t *bins, float *notes, float *notes_voiced, vit_stream stream);
+
+/*
+ * Device-resident hand-off from the acoustic model (replaces the host round trip at tonet/for_paper.py:2282-2302): a
+ * batch of snippets [n_snippets, n_channels, n_frames] float32 (channel 0 = unvoiced) is transposed into time-major logit
+ * rows appended at rows_out (device; the caller advances the pointer recording by recording):
+ *   mode 0 ("shaun"):   n_channels-1 columns, channel 0 subtracted (:2296-2297);  mode 1 ("softmax"): n_channels columns.
+ * Only the first n_rows <= n_snippets * n_frames rows are written (the last batch of a recording is padded, :2299-2300).
+ */
+int vit_snippets_append(const float *snippets, int32_t n_snippets, int32_t n_channels, int32_t n_frames, int32_t mode,
+                        float *rows_out, int64_t n_rows, vit_stream stream);
+
 /*
  * Emission builders (the step upstream of the decoder): pitch logits -> log(p + tiny)
  * observation log-probabilities in the [n_frames, n_bins+1] layout vit_decode() reads (unvoiced state last).
@@ -163,12 +179,19 @@ int vit_voicing_map(const int32_t *states, int64_t n, int32_t n_bins, uint8_t *v
  *                     spw = single-side peak width (5).
  *   vit_obs_softmax : SoftMaxViterbi.observation_probs_fn, tonet/for_paper.py:1911-1944 -- logits
  *                     [n_frames, n_bins+1] with column 0 = unvoiced; spw = 15.
+ *   vit_obs_softmax_scaled : dcnet's SoftMaxViterbi.observation_probs_fn, dcnet/softmax_viterbi.py:2530-2579 -- logits
+ *                     [n_frames, n_bins]; the unvoiced logit is the constant unvoiced_logit = log(vth/(1-vth)) (:2548-2550);
+ *                     every softmax probability is divided by its state prior ("scaled likelihood", values may exceed 1,
+ *                     i.e. positive log-emissions); prior: device, [n_bins+1] float32 in state order (unvoiced last), or NULL
+ *                     for the unscaled variant; a frame without peaks gets 1 / prior[unvoiced] (:2562-2565); spw = 5.
  * exp/log run on the GPU: probabilities agree with the reference to a few ulp, structural zeros are exact.
  */
 int vit_obs_shaun(const float *logits, int64_t n_frames, int32_t n_bins, int32_t spw, double threshold_logit,
                   double offset, double scale, float *logE, vit_stream stream);
 int vit_obs_softmax(const float *logits, int64_t n_frames, int32_t n_bins, int32_t spw, float *logE,
                     vit_stream stream);
+int vit_obs_softmax_scaled(const float *logits, int64_t n_frames, int32_t n_bins, int32_t spw, double unvoiced_logit,
+                           const float *prior, float *logE, vit_stream stream);
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,10 @@ Python per-frame loops that sit right upstream of the Viterbi decoder (SURVEY.md
 * :func:`softmax_observation_probs` -- SoftMaxViterbi.observation_probs_fn, tonet/for_paper.py:1890-1944
   (softmax over the peak set with a +/-15-bin window, unvoiced logit first, rolled to the last state).
 
+* :func:`softmax_scaled_observation_probs` -- dcnet's SoftMaxViterbi.observation_probs_fn,
+  dcnet/softmax_viterbi.py:2530-2579 ("scaled likelihood": softmax over the peak set divided by the state prior,
+  unvoiced logit = the padded voicing-threshold logit, +/-5-bin window; values may exceed 1).
+
 Pinned: tests/golden/make_obs_goldens.py runs the reference's own methods (AST-extracted) on seeded
 logits and commits inputs' seeds + outputs; tests compare these restatements bit for bit.
 """
@@ -84,5 +88,35 @@ def softmax_observation_probs(logits: np.ndarray, spw: int = 15) -> np.ndarray:
         pk = pk - np.max(pk)
         pk = np.exp(pk)
         pk = pk / np.sum(pk)
+        out[f, idx] = pk
+    return np.roll(out, shift=-1, axis=1)
+
+
+def softmax_scaled_observation_probs(logits: np.ndarray, voicing_threshold_prob: float, ini_probs: np.ndarray,
+                                     scaled: bool = True, spw: int = 5) -> np.ndarray:
+    """logits float32 [n_frames, n_bins] -> scaled likelihoods float32 [n_frames, n_bins+1], unvoiced state LAST.
+    ini_probs: the state prior [n_bins+1] (unvoiced last), as loaded from viterbi_init_probs.dat."""
+    assert logits.dtype == np.float32 and logits.ndim == 2
+    n_frames, n_bins = logits.shape
+    if scaled:
+        prior = np.roll(np.asarray(ini_probs), 1).astype(np.float32)      # unvoiced first, like the padded logits
+    else:
+        prior = np.ones([n_bins + 1], np.float32)
+    vth = np.log(voicing_threshold_prob / (1. - voicing_threshold_prob))
+    lg = np.pad(logits, [[0, 0], [1, 0]], mode="constant", constant_values=vth)
+    is_peak = np.zeros((n_frames, n_bins + 1), np.bool_)
+    is_peak[:, 0] = True
+    is_peak[:, 1:] = _peaks(lg[:, 1:], spw)
+    out = np.zeros((n_frames, n_bins + 1), np.float32)
+    for f in range(n_frames):
+        idx = np.where(is_peak[f])[0]
+        if len(idx) == 1:
+            out[f, 0] = 1. / prior[0]
+            continue
+        pk = lg[f, idx]
+        np.subtract(pk, np.max(pk), out=pk)
+        np.exp(pk, out=pk)
+        np.divide(pk, np.sum(pk), out=pk)
+        np.divide(pk, prior[idx], out=pk)
         out[f, idx] = pk
     return np.roll(out, shift=-1, axis=1)

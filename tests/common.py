@@ -6,7 +6,8 @@ import torch
 
 from viterbi_spl_amd import synth
 
-GEN = {"peaks": synth.emissions_peaks, "dense": synth.emissions_dense, "ties": synth.emissions_ties}
+GEN = {"peaks": synth.emissions_peaks, "dense": synth.emissions_dense, "ties": synth.emissions_ties,
+       "scaled": synth.emissions_scaled}
 
 
 def case_params(golden, case):

@@ -84,20 +84,62 @@ def test_decode_refuses_cpu_tensors(golden):
         v.decode(torch.zeros(3, 321), golden["params"]["msnet321_logA_T"], golden["params"]["msnet321_log_pi"])
 
 
-def test_host_emission_builders_match_reference_goldens(golden, monkeypatch):
-    """The adapters' host-exact builders (used with exact_emissions=True) reproduce the reference bit for bit.
-    Constructed without a GPU: only the NumPy methods are exercised."""
+def test_scaled_observation_oracle_matches_reference_goldens(golden):
+    """dcnet's scaled-likelihood builder (dcnet/softmax_viterbi.py:2530-2579): the oracle restatement equals the
+    reference's own outputs (values far above 1: positive log-emissions)."""
     import os
+    from oracle import observation_oracle as oo
     from tests.common import logits_case
-    from viterbi_spl_amd import reference_api as ra
     og = np.load(os.path.join(os.path.dirname(__file__), "golden", "obs_goldens.npz"))
-    v = ra.Viterbi.__new__(ra.Viterbi)
-    v.num_freq_bins, v.single_side_peak_width, v.threshold = 360, 5, np.log(0.32 / (1. - 0.32))
-    s = ra.SoftMaxViterbi.__new__(ra.SoftMaxViterbi)
-    s.num_freq_bins, s.single_side_peak_width = 360, 15
-    for k in range(3):
-        seed, n = og[f"shaun{k}_seed"]
-        got = v.observation_probs_fn(logits_case(int(seed), int(n), 360))
-        assert got.flags["F_CONTIGUOUS"] and np.array_equal(np.ascontiguousarray(got.T), og[f"shaun{k}_probs"])
-        seed, n = og[f"softmax{k}_seed"]
-        assert np.array_equal(s.observation_probs_fn(logits_case(int(seed), int(n), 361)), og[f"softmax{k}_probs"])
+    prior = golden["params"]["msnet321_pi"]
+    for k in range(4):
+        seed, n = og[f"scaled{k}_seed"]
+        vth, scaled = og[f"scaled{k}_vth"]
+        got = oo.softmax_scaled_observation_probs(logits_case(int(seed), int(n), 320), np.float32(vth), prior, scaled=bool(scaled))
+        assert np.array_equal(got, og[f"scaled{k}_probs"])
+    assert og["scaled0_probs"].max() > 1000
+
+
+def test_parameter_recipes_match_the_reference_scripts(golden):
+    """viterbi_spl_amd/params.py against the outputs of the reference's own post-processing scripts (run with stubbed
+    I/O by tests/golden/make_param_goldens.py): banded Toeplitz transition from counts, floored prior."""
+    import json
+    import os
+    from viterbi_spl_amd import params
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    pg = np.load(os.path.join(gdir, "param_goldens.npz"))
+    assert params.single_side_d_max_fn(h=0.01, B=60) == 14                 # tonet
+    assert params.single_side_d_max_fn(h=0.01, B=240) == 56                # imm (imm/viterbi_transition_post_processing.py:44)
+    A = params.toeplitz_from_counts(pg["counts360"].astype(np.int64), 14)
+    assert A.dtype == np.float32 and A.tobytes() == pg["transition360"].tobytes()
+    assert np.count_nonzero(A[100]) == 30 and np.count_nonzero(A[360]) == 361 and np.allclose(A.sum(axis=1), 1)
+    pi = params.floored_prior(pg["p_steady361"])
+    assert pi.dtype == np.float32 and pi.tobytes() == pg["init_probs361"].tobytes()
+    assert pi[:-1].min() >= 0.9 * (1.0 / 361 / 10.0) * (1 - pi[-1])
+    # ... and the structure analyser takes the recipe's output: band + unvoiced row / column, wave form available
+    from tests.plan_replay import HostPlan
+    plan = HostPlan(*synth.log_params(A, pi))
+    assert plan.ok and plan.max_window == 29 and plan.extras == [360] and plan.floor_ok and plan.wave_ok
+    # Durrieu's matrix and the shipped .dat files: hashes recorded from the reference in the build container
+    man = json.load(open(os.path.join(gdir, "param_manifest.json")))
+    import hashlib
+    for bps, nb in ((20, 721), (20, 720), (5, 180)):
+        assert hashlib.sha256(synth.durrieu_transition(nb, bps).tobytes()).hexdigest() == man[f"durrieu_{bps}_{nb}_sha256"]
+
+
+def test_datfile_reads_the_shipped_parameter_files(golden, tmp_path):
+    """The two parameter files the reference ships (msnet/viterbi_*.dat) are rebuilt byte for byte from the committed
+    arrays + recorded header (SHA-256 recorded from the real files) and read back with datfile.py."""
+    import hashlib
+    import json
+    import os
+    man = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "param_manifest.json")))
+    for fname in ("viterbi_transition_matrix.dat", "viterbi_init_probs.dat"):
+        rec = man[fname]
+        arr = golden["params"][rec["params_key"]]
+        raw = rec["header"].encode() + arr.tobytes()
+        assert hashlib.sha256(raw).hexdigest() == rec["sha256"]
+        f = tmp_path / fname
+        f.write_bytes(raw)
+        name, got = datfile.load_np_array_from_file_fn(str(f))
+        assert name == fname[:-4] and got.dtype == arr.dtype and got.shape == arr.shape and got.tobytes() == arr.tobytes()

@@ -19,7 +19,7 @@ ALGO = {"auto": 0, "dense": 1, "banded": 2, "wave": 3, "group": 4}
 EXPORTS = (
     "vit_abi_version", "vit_status_string", "vit_last_hip_error", "vit_plan_create", "vit_plan_destroy",
     "vit_plan_query", "vit_plan_image_bytes", "vit_plan_upload", "vit_workspace_bytes", "vit_decode",
-    "vit_forward", "vit_backtrace", "vit_voicing_map", "vit_obs_shaun", "vit_obs_softmax", "vit_plan_set_option",
+    "vit_forward", "vit_backtrace", "vit_voicing_map", "vit_obs_shaun", "vit_obs_softmax", "vit_obs_softmax_scaled", "vit_plan_set_option", "vit_snippets_append", "vit_voicing_notes",
 )
 ABI_VERSION = 2
 
@@ -90,6 +90,12 @@ def load() -> ctypes.CDLL:
     lib.vit_obs_shaun.argtypes = [vp, i64, i32, i32, f64, f64, f64, vp, vp]
     lib.vit_obs_softmax.restype = i32
     lib.vit_obs_softmax.argtypes = [vp, i64, i32, i32, vp, vp]
+    lib.vit_obs_softmax_scaled.restype = i32
+    lib.vit_obs_softmax_scaled.argtypes = [vp, i64, i32, i32, f64, vp, vp, vp]
+    lib.vit_snippets_append.restype = i32
+    lib.vit_snippets_append.argtypes = [vp, i32, i32, i32, i32, vp, i64, vp]
+    lib.vit_voicing_notes.restype = i32
+    lib.vit_voicing_notes.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp]
     lib.vit_debug_scan.restype = i32
     lib.vit_debug_scan.argtypes = [vp, i32, i32, vp, vp, vp]
     _lib = lib

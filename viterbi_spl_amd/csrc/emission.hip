@@ -3,6 +3,8 @@
 // the frames of a song on the host:
 //   Viterbi.observation_probs_fn          tonet/for_paper.py:1733-1778  (+ find_peaks :1714-1731, expit :1703-1712)
 //   SoftMaxViterbi.observation_probs_fn   tonet/for_paper.py:1911-1944  (+ find_peaks :1890-1909)
+//   SoftMaxViterbi.observation_probs_fn   dcnet/softmax_viterbi.py:2530-2579  ("scaled likelihood": p / prior, unvoiced
+//                                         logit = the voicing-threshold logit; values may exceed 1)
 // followed by log(p + tiny) in viterbi_librosa_fn (:1846-1847).  Here one wave builds one frame and
 // writes log(p + tiny) directly in the [frames, n_bins+1] layout vit_decode() reads.
 //
@@ -32,19 +34,22 @@ __device__ __forceinline__ float wave_max_f(float x) {
     return x;
 }
 
-// MODE 0: "shaun" (soft voicing on the strongest peak); MODE 1: softmax over the peak set.
-// logits: MODE 0 [n_frames, U]; MODE 1 [n_frames, U+1] with column 0 = unvoiced.  out: [n_frames, U+1].
+// MODE 0: "shaun" (soft voicing on the strongest peak); MODE 1: softmax over the peak set; MODE 2: softmax over the
+// peak set with a constant unvoiced logit (`threshold`), every probability divided by its state prior.
+// logits: MODE 0, 2 [n_frames, U]; MODE 1 [n_frames, U+1] with column 0 = unvoiced.  out: [n_frames, U+1].
+// prior (MODE 2): [U+1] in state order (unvoiced last), or null for no scaling.
 template <int EPL, int MODE>
 __global__ void __launch_bounds__(kObsWaves * 64) observation_kernel(const float* __restrict__ logits, int64_t n_frames,
                                                                      int U, int spw, double threshold, double offset,
-                                                                     double scale, float* __restrict__ out) {
+                                                                     double scale, const float* __restrict__ prior,
+                                                                     float* __restrict__ out) {
     extern __shared__ float smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int PW = U + 2 * spw;                       // reflect-padded row
     float* row = smem + (size_t)wv * (PW + 1);
-    const int in_stride = MODE == 0 ? U : U + 1;
-    const int in_off = MODE == 0 ? 0 : 1;
+    const int in_stride = MODE == 1 ? U + 1 : U;
+    const int in_off = MODE == 1 ? 1 : 0;
     const int S = U + 1;
 
     for (int64_t f = (int64_t)blockIdx.x * kObsWaves + wv; f < n_frames; f += (int64_t)gridDim.x * kObsWaves) {
@@ -76,10 +81,11 @@ __global__ void __launch_bounds__(kObsWaves * 64) observation_kernel(const float
                 if (is) lmax = fmaxf(lmax, c);
             }
         }
-        const float x0 = MODE == 1 ? logits[f * in_stride] : -INFINITY;   // unvoiced logit: always in the peak set
+        // unvoiced logit: always in the peak set (MODE 2: the padded voicing-threshold logit, rounded to float32 like np.pad)
+        const float x0 = MODE == 1 ? logits[f * in_stride] : (MODE == 2 ? (float)threshold : -INFINITY);
         float g = wave_max_f(lmax);
         const bool any_peak = g > -INFINITY;
-        if (MODE == 1) g = fmaxf(g, x0);
+        if (MODE >= 1) g = fmaxf(g, x0);
         float ex[EPL];
         float lsum = 0.f;
 #pragma unroll
@@ -113,16 +119,18 @@ __global__ void __launch_bounds__(kObsWaves * 64) observation_kernel(const float
                 float p;
                 if (MODE == 0) p = (float)((double)ex[e] * t);
                 else p = any_peak ? ex[e] / tot : 0.f;
+                if (MODE == 2 && prior) p = p / prior[b];        // two float32 divisions, like the reference
                 o[b] = pk[e] ? logf(p + kTiny) : kLogTiny;
             }
         }
+        if (MODE == 2 && prior) last = last / prior[U];          // a peak-less frame: 1 / prior
         if (lane == 0) o[U] = logf(last + kTiny);
     }
 }
 
 template <int MODE>
 static hipError_t launch_obs(const float* logits, int64_t n_frames, int U, int spw, double thr, double off, double sc,
-                             float* out, hipStream_t st) {
+                             const float* prior, float* out, hipStream_t st) {
     if (n_frames <= 0) return hipSuccess;
     if (spw < 1 || spw >= U || spw > 64 || U > 768) return hipErrorInvalidValue;
     int64_t blocks = (n_frames + kObsWaves - 1) / kObsWaves;
@@ -130,19 +138,87 @@ static hipError_t launch_obs(const float* logits, int64_t n_frames, int U, int s
     const size_t lds = sizeof(float) * kObsWaves * (U + 2 * spw + 1);
     if (U <= 384)
         hipLaunchKernelGGL((observation_kernel<6, MODE>), dim3((int)blocks), dim3(kObsWaves * 64), lds, st, logits, n_frames, U,
-                           spw, thr, off, sc, out);
+                           spw, thr, off, sc, prior, out);
     else
         hipLaunchKernelGGL((observation_kernel<12, MODE>), dim3((int)blocks), dim3(kObsWaves * 64), lds, st, logits, n_frames, U,
-                           spw, thr, off, sc, out);
+                           spw, thr, off, sc, prior, out);
     return hipGetLastError();
 }
 
 hipError_t launch_obs_shaun(const float* logits, int64_t n_frames, int U, int spw, double thr, double off, double sc,
                             float* out, hipStream_t st) {
-    return launch_obs<0>(logits, n_frames, U, spw, thr, off, sc, out, st);
+    return launch_obs<0>(logits, n_frames, U, spw, thr, off, sc, nullptr, out, st);
 }
 hipError_t launch_obs_softmax(const float* logits, int64_t n_frames, int U, int spw, float* out, hipStream_t st) {
-    return launch_obs<1>(logits, n_frames, U, spw, 0.0, 0.0, 0.0, out, st);
+    return launch_obs<1>(logits, n_frames, U, spw, 0.0, 0.0, 0.0, nullptr, out, st);
+}
+hipError_t launch_obs_softmax_scaled(const float* logits, int64_t n_frames, int U, int spw, double unvoiced_logit,
+                                     const float* prior, float* out, hipStream_t st) {
+    return launch_obs<2>(logits, n_frames, U, spw, unvoiced_logit, 0.0, 0.0, prior, out, st);
+}
+
+// ---------------------------------------------------------------------------------------
+// Device-resident hand-off from the acoustic model (tonet/for_paper.py:2282-2302 does this on the
+// host after a .cpu().numpy() copy): a batch of snippets [n, C, F] (C = n_bins + 1 channel rows, channel 0 = unvoiced,
+// F frames) becomes n*F time-major logit rows appended to a recording's buffer on the GPU --
+//   mode 0 ("shaun"):   row[b] = snip[b+1][f] - snip[0][f]   (n_bins columns: logits relative to the unvoiced channel)
+//   mode 1 ("softmax"): row[c] = snip[c][f]                  (n_bins + 1 columns, unvoiced first)
+// Only the first `rows` (= n*F - padded_frames) rows are written.  A 64 x 64 tile goes through LDS so that both the
+// frame-contiguous reads and the channel-contiguous writes are coalesced.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) snippets_append_kernel(const float* __restrict__ snips, int n, int C, int F, int mode,
+                                                              float* __restrict__ out, int64_t rows) {
+    __shared__ float tile[64][65];
+    __shared__ float ch0[64];
+    const int sn = blockIdx.z, c0 = blockIdx.y * 64, f0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 64 x 4
+    const float* __restrict__ src = snips + (size_t)sn * C * F;
+    const int cols = mode == 0 ? C - 1 : C;
+    const int coff = mode == 0 ? 1 : 0;                         // first channel that becomes a column
+    for (int r = ty; r < 64; r += 4) {
+        const int c = c0 + r + coff, f = f0 + tx;
+        tile[r][tx] = (c < C && f < F) ? src[(size_t)c * F + f] : 0.f;
+    }
+    if (mode == 0 && threadIdx.x < 64) ch0[tx] = f0 + tx < F ? src[f0 + tx] : 0.f;
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int f = f0 + r, col = c0 + tx;
+        const int64_t row = (int64_t)sn * F + f;
+        if (f < F && col < cols && row < rows) out[row * cols + col] = mode == 0 ? tile[tx][r] - ch0[r] : tile[tx][r];
+    }
+}
+
+hipError_t launch_snippets_append(const float* snips, int n, int C, int F, int mode, float* out, int64_t rows, hipStream_t st) {
+    if (n <= 0 || rows <= 0) return hipSuccess;
+    const int cols = mode == 0 ? C - 1 : C;
+    hipLaunchKernelGGL(snippets_append_kernel, dim3((F + 63) / 64, (cols + 63) / 64, n), dim3(256), 0, st, snips, n, C, F, mode, out, rows);
+    return hipGetLastError();
+}
+
+// voiced = state < n_bins; bins = min(state, n_bins-1); notes = note_range[bins]; notes_v = voiced ? notes : 0
+// (tonet/for_paper.py:1828-1829, :2106-2115 est_notes_360_fn, :2207)
+__global__ void voicing_notes_kernel(const int32_t* __restrict__ states, int64_t n, int32_t n_bins,
+                                     const float* __restrict__ note_range, uint8_t* __restrict__ voiced,
+                                     int32_t* __restrict__ bins, float* __restrict__ notes, float* __restrict__ notes_v) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t s = states[i];
+        const bool v = s >= 0 && s < n_bins;
+        const int32_t b = s < 0 ? -1 : (s < n_bins - 1 ? s : n_bins - 1);
+        const float nt = b >= 0 ? note_range[b] : 0.f;
+        if (voiced) voiced[i] = v ? 1 : 0;
+        if (bins) bins[i] = b;
+        if (notes) notes[i] = nt;
+        if (notes_v) notes_v[i] = v ? nt : 0.f;
+    }
+}
+
+hipError_t launch_voicing_notes(const int32_t* states, int64_t n, int32_t n_bins, const float* note_range, uint8_t* voiced,
+                                int32_t* bins, float* notes, float* notes_v, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(voicing_notes_kernel, dim3((int)blocks), dim3(256), 0, st, states, n, n_bins, note_range, voiced, bins, notes, notes_v);
+    return hipGetLastError();
 }
 
 }  // namespace vit

@@ -105,6 +105,11 @@ hipError_t launch_scan_selftest(const float* vals, int n_waves, int mode, float*
 hipError_t launch_obs_shaun(const float* logits, int64_t n_frames, int U, int spw, double thr, double off, double sc,
                             float* out, hipStream_t st);
 hipError_t launch_obs_softmax(const float* logits, int64_t n_frames, int U, int spw, float* out, hipStream_t st);
+hipError_t launch_obs_softmax_scaled(const float* logits, int64_t n_frames, int U, int spw, double unvoiced_logit,
+                                     const float* prior, float* out, hipStream_t st);
+hipError_t launch_snippets_append(const float* snips, int n, int C, int F, int mode, float* out, int64_t rows, hipStream_t st);
+hipError_t launch_voicing_notes(const int32_t* states, int64_t n, int32_t n_bins, const float* note_range, uint8_t* voiced,
+                                int32_t* bins, float* notes, float* notes_v, hipStream_t st);
 int backtrace_tile_rows(int SD);
 constexpr int kBtWarm = 128;       // warm-up frames of a speculative chunk (survivor paths coalesce within tens of frames)
 constexpr int kBtMaxChunks = 32;

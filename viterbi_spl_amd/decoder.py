@@ -18,6 +18,7 @@ libviterbi_hip.so.  Nothing in this module falls back to the CPU.
 from __future__ import annotations
 
 import ctypes
+import hashlib
 from typing import Optional, Tuple
 
 import numpy as np
@@ -189,6 +190,25 @@ class ViterbiDecoder:
         return voiced.bool(), bins
 
 
+    def voicing_notes(self, states: torch.Tensor, note_range, n_bins: Optional[int] = None):
+        """(voiced, bins, notes): the voicing map plus ``notes = note_range[bins]`` with 0 where unvoiced
+        (tonet/for_paper.py:2106-2115, :2207), all on the GPU."""
+        n_bins = self.S - 1 if n_bins is None else int(n_bins)
+        st = states.to(torch.int32).contiguous()
+        nr = note_range if isinstance(note_range, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(note_range, np.float32))
+        nr = nr.to(device=st.device, dtype=torch.float32).contiguous()
+        if tuple(nr.shape) != (n_bins,):
+            raise ValueError(f"note_range must have {n_bins} entries")
+        voiced = torch.empty(st.shape, dtype=torch.uint8, device=st.device)
+        bins = torch.empty(st.shape, dtype=torch.int32, device=st.device)
+        notes = torch.empty(st.shape, dtype=torch.float32, device=st.device)
+        with torch.cuda.device(st.device):
+            rc = _lib.load().vit_voicing_notes(st.data_ptr(), st.numel(), n_bins, nr.data_ptr(), voiced.data_ptr(), bins.data_ptr(),
+                                               None, notes.data_ptr(), torch.cuda.current_stream(st.device).cuda_stream)
+        _lib.check(rc, "vit_voicing_notes")
+        return voiced.bool(), bins, notes
+
+
 _DECODERS: dict = {}
 
 
@@ -200,7 +220,7 @@ def get_decoder(transition_matrix, init_probs, device=None) -> ViterbiDecoder:
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     if dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
-    key = (hash(A.tobytes()), hash(pi.tobytes()), A.shape, str(dev))
+    key = (hashlib.sha256(A.tobytes()).digest(), hashlib.sha256(pi.tobytes()).digest(), A.shape, str(dev))
     dec = _DECODERS.get(key)
     if dec is None:
         if len(_DECODERS) >= 8:

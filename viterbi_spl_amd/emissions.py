@@ -55,3 +55,25 @@ def softmax_log_emissions(logits: torch.Tensor, single_side_peak_width: int = 15
                                          torch.cuda.current_stream(logits.device).cuda_stream)
     _lib.check(rc, "vit_obs_softmax")
     return out
+
+
+def softmax_scaled_log_emissions(logits: torch.Tensor, voicing_threshold_prob: float, prior: torch.Tensor | None,
+                                 single_side_peak_width: int = 5) -> torch.Tensor:
+    """dcnet's ``SoftMaxViterbi.observation_probs_fn`` (dcnet/softmax_viterbi.py:2530-2579) + log: logits ``[..., T, n_bins]``
+    -> log of the scaled likelihoods ``[..., T, n_bins+1]`` (unvoiced last; values above 0 are normal).  ``prior``: the
+    state prior ``[n_bins+1]`` (unvoiced last) on the GPU, or None for the unscaled variant."""
+    n_bins = logits.shape[-1]
+    logits = _check(logits, n_bins)
+    assert 0 < voicing_threshold_prob < 1
+    if prior is not None:
+        if prior.device != logits.device or prior.dtype != torch.float32 or tuple(prior.shape) != (n_bins + 1,) or not prior.is_contiguous():
+            raise ValueError(f"prior must be a contiguous float32 [{n_bins + 1}] tensor on the logits' device")
+    out = torch.empty(logits.shape[:-1] + (n_bins + 1,), dtype=torch.float32, device=logits.device)
+    n = logits.numel() // n_bins
+    with torch.cuda.device(logits.device):
+        rc = _lib.load().vit_obs_softmax_scaled(logits.data_ptr(), n, n_bins, single_side_peak_width,
+                                                math.log(voicing_threshold_prob / (1.0 - voicing_threshold_prob)),
+                                                prior.data_ptr() if prior is not None else None, out.data_ptr(),
+                                                torch.cuda.current_stream(logits.device).cuda_stream)
+    _lib.check(rc, "vit_obs_softmax_scaled")
+    return out

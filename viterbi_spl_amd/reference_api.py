@@ -113,6 +113,7 @@ class _PreparedViterbi:
         p = np.require(p, np.float32)
         p.flags['WRITEABLE'] = False
         self.log_ini_probs = p
+        self.ini_probs = init_probs
         self._decoder = ViterbiDecoder(t, p, device)
 
     @classmethod
@@ -130,16 +131,30 @@ class _PreparedViterbi:
         bins = np.minimum(bins, n_bins - 1)
         return voiced, bins
 
+    # ---- the post-processor on the GPU: logits -> log-emissions -> decode -> (voiced, bins)
+    def _log_emissions(self, logits: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
 
-def _find_peaks(frames_logits, spw):
-    """find_peaks_all_at_once_np_fn (tonet/for_paper.py:1714-1731): first maximum of the reflect-padded window."""
-    n_frames, n_bins = frames_logits.shape
-    padded = np.pad(frames_logits, [(0, 0), (spw, spw)], mode='reflect')
-    w = 2 * spw + 1
-    are_peaks = np.zeros([n_frames, n_bins], np.bool_)
-    for bin_idx in range(n_bins):
-        are_peaks[:, bin_idx] = np.argmax(padded[:, bin_idx:bin_idx + w], axis=1) == spw
-    return are_peaks
+    def decode_logits(self, logits, note_range=None):
+        """Whole post-processor with everything on the GPU.  logits: NumPy or torch, ``[frames, columns]``.
+        Returns torch tensors on the decoder's device: ``(voiced bool[T], bins int32[T])``, plus ``notes float32[T]``
+        (``note_range[bins]``, 0 where unvoiced: tonet/for_paper.py:2106-2115, :2207) when ``note_range`` is given."""
+        lg = logits if isinstance(logits, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(logits, np.float32))
+        lg = lg.to(self._decoder.device).contiguous()
+        states, _ = self._decoder.decode(self._log_emissions(lg), out_dtype=torch.int32)
+        if note_range is None:
+            return self._decoder.voicing(states, self.num_freq_bins)
+        return self._decoder.voicing_notes(states, note_range, self.num_freq_bins)
+
+    def __call__(self, logits):
+        """``viterbi(logits) -> (voiced bool[T], bins int64[T])`` as NumPy arrays, the reference's call surface
+        (tonet/for_paper.py:1817-1831, :2309).  The observation probabilities are built on the GPU (``vit_obs_*``: peak
+        picking, voicing decision and structural zeros exact; exp / log / sums within a few ulp of NumPy's, see
+        tests/test_gpu_parity.py::test_default_postprocessor_path_agreement for the measured path agreement).  Callers
+        that need the reference's bits end to end build the probabilities themselves and call
+        :meth:`viterbi_librosa_fn`, which is exact."""
+        voiced, bins = self.decode_logits(logits)
+        return voiced.cpu().numpy(), bins.cpu().numpy().astype(np.int64)
 
 
 class Viterbi(_PreparedViterbi):
@@ -154,43 +169,6 @@ class Viterbi(_PreparedViterbi):
         self.threshold = np.log(voicing_threshold / (1. - voicing_threshold))
         self.single_side_peak_width = 5
 
-    @staticmethod
-    def expit(s):
-        if s > 0:
-            return 1. / (1. + np.exp(-s))
-        p = np.exp(s)
-        return p / (1. + p)
-
-    def observation_probs_fn(self, logits):
-        """Host NumPy builder, operation for operation the reference's (:1733-1778): bit-exact, slow."""
-        assert isinstance(logits, np.ndarray) and logits.dtype == np.float32
-        n_frames, n_freq_bins = logits.shape
-        assert n_freq_bins == self.num_freq_bins
-        offset = np.log(0.8 / (1. - 0.8))
-        scale = 2.
-        melodies_frames = np.zeros([n_freq_bins + 1, n_frames], np.float32, order='F')
-        are_peaks = _find_peaks(logits, self.single_side_peak_width)
-        for frame_idx in range(n_frames):
-            peak_indices = np.where(are_peaks[frame_idx])[0]
-            if len(peak_indices) == 0:
-                melodies_frames[-1, frame_idx] = 1
-                continue
-            peak_logits = logits[frame_idx][peak_indices]
-            g = peak_logits[np.argmax(peak_logits)]
-            if g >= self.threshold:
-                s = scale * (g - self.threshold) + offset
-            else:
-                s = scale * (g - self.threshold) - offset
-            p_voiced = Viterbi.expit(s)
-            peak_logits -= g
-            np.exp(peak_logits, out=peak_logits)
-            t = p_voiced / np.sum(peak_logits)
-            np.multiply(peak_logits, t, out=peak_logits)
-            melodies_frames[peak_indices, frame_idx] = peak_logits
-            melodies_frames[-1, frame_idx] = 1. - p_voiced
-        assert np.all(np.isclose(np.sum(melodies_frames, axis=0), 1))
-        return melodies_frames
-
     def viterbi_librosa_fn(self, probs_st):
         S = self.num_freq_bins + 1
         assert probs_st.shape[0] == S
@@ -201,49 +179,19 @@ class Viterbi(_PreparedViterbi):
         probs = np.require(probs_st.T, np.float32, ['C'])
         return _run(self.log_transition_matrix_T, self.log_ini_probs, probs, self._decoder)
 
-    def __call__(self, logits, exact_emissions=False):
-        """logits: [n_frames, n_bins] float32 (NumPy, or a torch tensor already on the GPU).
-        exact_emissions=True builds the observation probabilities on the host exactly like the reference
-        (bit-exact end to end); the default builds them on the GPU (vit_obs_shaun: same decisions, exp/log
-        within a few ulp) so that GPU-resident logits never visit the host."""
-        if exact_emissions:
-            lg = logits.detach().cpu().numpy() if isinstance(logits, torch.Tensor) else logits
-            return self._post(self.viterbi_librosa_fn(self.observation_probs_fn(lg)))
+    def _log_emissions(self, logits):
         from .emissions import shaun_log_emissions
-        lg = logits if isinstance(logits, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(logits, np.float32))
-        lg = lg.to(self._decoder.device).contiguous()
-        logE = shaun_log_emissions(lg, self.voicing_threshold, self.single_side_peak_width)
-        states, _ = self._decoder.decode(logE, out_dtype=torch.int64)
-        return self._post(states.cpu().numpy())
+        return shaun_log_emissions(logits, self.voicing_threshold, self.single_side_peak_width)
 
 
 class SoftMaxViterbi(_PreparedViterbi):
     """Family C (tonet/for_paper.py:1873-2037): C-contiguous [T, S] probabilities (values may
-    exceed 1 for scaled likelihoods), logged IN PLACE.  ``__call__(logits)`` as above."""
+    exceed 1 for scaled likelihoods), logged IN PLACE.  ``__call__(logits)`` as above; logits carry the unvoiced
+    column first ([T, n_bins+1])."""
 
     def __init__(self, transition_matrix, init_probs, num_freq_bins=None, device=None):
         super().__init__(transition_matrix, init_probs, num_freq_bins, device)
         self.single_side_peak_width = 15
-
-    def observation_probs_fn(self, logits):
-        """Host NumPy builder following :1911-1944 (unvoiced logit first, rolled to the last state)."""
-        assert isinstance(logits, np.ndarray) and logits.dtype == np.float32 and logits.ndim == 2
-        assert logits.shape[1] == self.num_freq_bins + 1 and logits.flags['C_CONTIGUOUS']
-        n_frames, n_bins = len(logits), self.num_freq_bins
-        prob_ts = np.zeros([n_frames, 1 + n_bins], np.float32)
-        are_peaks_ts = np.zeros([n_frames, n_bins + 1], np.bool_)
-        are_peaks_ts[:, 0] = True
-        are_peaks_ts[:, 1:] = _find_peaks(logits[:, 1:], self.single_side_peak_width)
-        for frame_idx, are_peaks in enumerate(are_peaks_ts):
-            peak_indices = np.where(are_peaks)[0]
-            if len(peak_indices) == 1:
-                prob_ts[frame_idx, 0] = 1
-                continue
-            peak_logits = logits[frame_idx, peak_indices]
-            peak_logits = np.exp(peak_logits - np.max(peak_logits))
-            prob_ts[frame_idx, peak_indices] = peak_logits / np.sum(peak_logits)
-        assert np.allclose(np.sum(prob_ts, axis=1), 1)
-        return np.roll(prob_ts, shift=-1, axis=1)
 
     def viterbi_librosa_fn(self, probs_ts):
         S = self.num_freq_bins + 1
@@ -255,13 +203,77 @@ class SoftMaxViterbi(_PreparedViterbi):
         np.log(probs_ts, out=probs_ts)
         return _run(self.log_transition_matrix_T, self.log_ini_probs, probs_ts, self._decoder)
 
-    def __call__(self, logits, exact_emissions=False):
-        if exact_emissions:
-            lg = logits.detach().cpu().numpy() if isinstance(logits, torch.Tensor) else logits
-            return self._post(self.viterbi_librosa_fn(self.observation_probs_fn(np.ascontiguousarray(lg))))
+    def _log_emissions(self, logits):
         from .emissions import softmax_log_emissions
-        lg = logits if isinstance(logits, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(logits, np.float32))
-        lg = lg.to(self._decoder.device).contiguous()
-        logE = softmax_log_emissions(lg, self.single_side_peak_width)
-        states, _ = self._decoder.decode(logE, out_dtype=torch.int64)
-        return self._post(states.cpu().numpy())
+        return softmax_log_emissions(logits, self.single_side_peak_width)
+
+
+class ScaledSoftMaxViterbi(SoftMaxViterbi):
+    """dcnet's SoftMaxViterbi (dcnet/softmax_viterbi.py:2486-2674; same class in ftanet / jdc / msnet): logits carry
+    the n_bins pitch columns only, the unvoiced logit is the voicing-threshold logit, peaks use a +/-5-bin window and --
+    with ``scaled=True`` -- every softmax probability is divided by its state prior ("scaled likelihood": values far
+    above 1, i.e. positive log-emissions)."""
+
+    def __init__(self, transition_matrix, init_probs, voicing_threshold_prob, scaled, num_freq_bins=None, device=None):
+        super().__init__(transition_matrix, init_probs, num_freq_bins, device)
+        assert 0 < voicing_threshold_prob < 1
+        self.voicing_threshold_prob = float(voicing_threshold_prob)
+        self.scaled = bool(scaled)
+        self.single_side_peak_width = 5
+        if self.scaled:
+            assert self.ini_probs.min() > 0.3 / (self.num_freq_bins * 10)       # dcnet/softmax_viterbi.py:2536
+        self._prior_dev = torch.from_numpy(np.ascontiguousarray(self.ini_probs, np.float32)).to(self._decoder.device) if self.scaled else None
+
+    def _log_emissions(self, logits):
+        from .emissions import softmax_scaled_log_emissions
+        return softmax_scaled_log_emissions(logits, self.voicing_threshold_prob, self._prior_dev, self.single_side_peak_width)
+
+
+class RecordingAccumulator:
+    """Per-recording logits kept on the GPU (replaces tonet/for_paper.py:2282-2309, where every batch of snippets is
+    copied to the host, transposed, and the recording concatenated in NumPy before ``viterbi(logits)``).
+
+        acc = RecordingAccumulator(viterbi, max_frames)          # viterbi: Viterbi ("shaun") or SoftMaxViterbi
+        for batch in recording: acc.append(pitch_logits, padded_frames)   # [n_snippets, n_bins+1, frames] on the GPU
+        voiced, bins, notes = acc.finish(note_range)             # torch tensors on the GPU
+
+    ``append`` transposes the snippets into time-major rows directly behind the rows already held (one kernel:
+    ``vit_snippets_append``; "shaun" rows are relative to the unvoiced channel, :2296-2297), ``finish`` runs emission
+    builder, decoder, voicing map and the bin -> note gather without a host visit."""
+
+    def __init__(self, viterbi: _PreparedViterbi, max_frames: int):
+        self.viterbi = viterbi
+        self.mode = 0 if isinstance(viterbi, Viterbi) else 1
+        self.cols = viterbi.num_freq_bins + (0 if self.mode == 0 else 1)
+        dev = viterbi._decoder.device
+        self._rows = torch.empty((int(max_frames), self.cols), dtype=torch.float32, device=dev)
+        self.n_frames = 0
+
+    def reset(self):
+        self.n_frames = 0
+
+    def append(self, pitch_logits: torch.Tensor, padded_frames: int = 0):
+        from . import _lib
+        if not isinstance(pitch_logits, torch.Tensor) or pitch_logits.device != self._rows.device:
+            raise ValueError("pitch_logits must be a torch tensor on the decoder's device")
+        if pitch_logits.dtype != torch.float32 or pitch_logits.dim() != 3 or pitch_logits.shape[1] != self.viterbi.num_freq_bins + 1:
+            raise ValueError(f"pitch_logits must be float32 [snippets, {self.viterbi.num_freq_bins + 1}, frames]")
+        x = pitch_logits.contiguous()
+        n, C, F = x.shape
+        rows = n * F - int(padded_frames)
+        if rows < 0 or self.n_frames + rows > self._rows.shape[0]:
+            raise ValueError("recording longer than max_frames (or padded_frames out of range)")
+        with torch.cuda.device(x.device):
+            rc = _lib.load().vit_snippets_append(x.data_ptr(), n, C, F, self.mode, self._rows[self.n_frames:].data_ptr(), rows,
+                                                 torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(rc, "vit_snippets_append")
+        self.n_frames += rows
+
+    def logits(self) -> torch.Tensor:
+        """The recording so far: ``[n_frames, columns]`` on the GPU (a view)."""
+        return self._rows[: self.n_frames]
+
+    def finish(self, note_range=None):
+        out = self.viterbi.decode_logits(self.logits(), note_range)
+        self.reset()
+        return out

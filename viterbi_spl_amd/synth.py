@@ -102,6 +102,34 @@ def emissions_peaks(B: int, T: int, S: int, seed: int = 0, device="cpu", dtype=t
     return out
 
 
+def emissions_scaled(B: int, T: int, S: int, seed: int = 0, device="cpu", dtype=torch.float32,
+                     first_song: int = 0) -> torch.Tensor:
+    """Peak-sparse log-emissions of a "scaled likelihood" builder (p / prior, dcnet/softmax_viterbi.py:2571-2572 in the
+    reference): like :func:`emissions_peaks`, but peak values reach well ABOVE zero (up to +6: a posterior near 1 over a
+    prior of a few 1e-3) and the unvoiced state swings between -3 and +3; every other state exactly log(tiny)."""
+    out = torch.empty((B, T, S), dtype=dtype, device=device)
+    frames = torch.arange(T, dtype=torch.int64, device=device)
+    for b in range(B):
+        row = _row_hash(_song_base(seed ^ 0x3C6EF372, first_song + b), T, device)
+        e = torch.full((T, S), LOG_TINY32, dtype=torch.float32, device=device)
+        n_peaks = _mix32(row ^ 0x1100) % 5
+        for k in range(4):
+            pos = _mix32(row ^ (0x2100 + k)) % (S - 1)
+            val = 4.0 - (_mix32(row ^ (0x3100 + k)) % 2048).to(torch.float32) * (1.0 / 256.0)      # [-4, +4]
+            on = n_peaks > k
+            e[frames[on], pos[on]] = val[on]
+        note = _mix32((frames // 48) ^ _song_base(seed ^ 0x7F4A7C15, first_song + b))
+        voiced = (note % 4) != 0
+        centre = 2 + (note >> 8) % (S - 5)
+        pos = centre + (_mix32(row ^ 0x5100) % 5) - 2
+        val = 6.0 - (_mix32(row ^ 0x6100) % 512).to(torch.float32) * (1.0 / 256.0)                 # (+4, +6]
+        e[frames[voiced], pos[voiced]] = val[voiced]
+        u = 3.0 - (_mix32(row ^ 0x4100) % 1024).to(torch.float32) * (1.0 / 256.0)                  # (-1, +3]
+        e[:, S - 1] = torch.where(voiced, u - 2.0, u)
+        out[b] = e.to(dtype)
+    return out
+
+
 def emissions_ties(B: int, T: int, S: int, seed: int = 0, device="cpu", dtype=torch.float32) -> torch.Tensor:
     """Adversarial-tie emissions: values from {0, -1, -2} only, so many
     candidates coincide exactly and the lowest-index tie-break decides."""
