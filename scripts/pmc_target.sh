@@ -29,8 +29,10 @@ for k, d in rows.items():
     for c, v in sorted(d.items()):
         print(f"   {c:24s} n={len(v)} mean={sum(v)/len(v):.5g}")
 for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
-    print("# kernel stats")
-    print(open(f).read())
+    print("# kernel stats (vit:: kernels; rocprofv3 --kernel-trace --stats)")
+    for k, line in enumerate(open(f)):
+        if k == 0 or "vit::" in line:
+            print(line.rstrip())
 PY
 find $OUT -name "*counter_collection.csv" -delete
 find $OUT -name "*kernel_trace.csv" -delete

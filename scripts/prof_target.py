@@ -19,7 +19,8 @@ dec = ViterbiDecoder(A, pi, dev)
 for kv in sys.argv[5:]:
     k, v = kv.split("=")
     dec.set_option(k, int(v))
-E = synth.emissions_peaks(B, T, 361, seed=1234, device=dev)
+base = synth.emissions_peaks(min(B, 32), T, 361, seed=1234, device=dev)      # songs repeat with period 32 (generation time)
+E = base if B <= 32 else base.repeat((B + 31) // 32, 1, 1)[:B].contiguous()
 st = torch.empty((B, T), dtype=torch.int32, device=dev)
 ll = torch.empty((B,), dtype=torch.float32, device=dev)
 for _ in range(steps):

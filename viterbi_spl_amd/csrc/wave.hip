@@ -323,11 +323,16 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
 template <int NPL, int D, int NX, typename ET>
 static hipError_t launch_wave_x(const FwdArgs& a, hipStream_t st) {
     const int grid = (int)((a.B + 3) / 4);
-    // up to one wave per SIMD on the chip (1024 songs) the deeper prefetch of the 512-register form is free
+    // Emission rows in flight: four in the one-wave-per-SIMD form (up to 1024 songs: the 512-register budget is free
+    // there), three in the two-waves-per-SIMD form.  Measured at S = 361 fp32 (gpurun_out/wave_pf.log): B = 1024
+    // PF 2 / 3 / 4 / 6 / 8 -> 24.6 / 21.4 / 19.9 / 21.5 / 33.8 ms (6 and 8 push the weights into AGPRs / scratch);
+    // B = 2048 PF 2 / 3 -> 38.9 / 37.4 ms.  Non-temporal loads / stores: no effect.
+    // (a second extra column costs six more weight registers and a prefetch row)
+    constexpr int PF1 = NX == 2 ? 3 : 4, PF2 = NX == 2 ? 2 : 3;
     if (a.B <= 1024 && !(a.wave_flags & 1))
-        hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, 4, 1, ET>), dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF1, 1, ET>), dim3(grid), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, 2, 2, ET>), dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, ET>), dim3(grid), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
