@@ -211,6 +211,8 @@ def replay_wave(plan: HostPlan, logE):
             M = np.max(d)
             hist[t] = d
             hist[t, 0] = M
+            for e, x in enumerate(plan.extras):                                    # copies of the extra columns' delta
+                hist[t, 1 + e] = d[o + x]
     return hist, d[valid].copy()
 
 

@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
     const unsigned long long wmask = W >= 64 ? ~0ull : ((1ull << W) - 1ull);
     // aux loads: entry e of row r by lane r * 8 + e (two halves of eight rows)
     const int aux_e = lane & 7;
-    const int aux_col = aux_e == 0 ? a.mcol : (aux_e <= nx ? a.col0 + a.extras[(aux_e - 1) & (kMaxExtras - 1)] : a.mcol);
+    const int aux_col = aux_e == 0 ? a.mcol : (aux_e <= nx ? (a.xcol0 >= 0 ? a.xcol0 + aux_e - 1 : a.col0 + a.extras[(aux_e - 1) & (kMaxExtras - 1)]) : a.mcol);
     bool inS[EPL], xcol[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
@@ -321,7 +321,7 @@ hipError_t launch_backtrace_sparse(const BtArgs& a, hipStream_t st) {
 // second tile in registers (sixteen waves per CU at 1024 songs and up)
 int sparse_backtrace_chunks(int64_t B, int T) {
     long long c = (4 * 1024 + B - 1) / (B > 0 ? B : 1);
-    const long long cmax = T / (8 * kBtWarm) > 1 ? T / (8 * kBtWarm) : 1;
+    const long long cmax = T / (8 * kBtWarmSparse) > 1 ? T / (8 * kBtWarmSparse) : 1;
     c = c > cmax ? cmax : c;
     c = c > kBtMaxChunks ? kBtMaxChunks : c;
     return c < 1 ? 1 : (int)c;

@@ -35,7 +35,7 @@ struct FwdStamp {
     const void* ws = nullptr;
     int64_t B = 0, T = 0;
     int family = 0;            // 1 dense / step, 2 banded (one song per workgroup), 3 wave
-    int SD = 0, col0 = 0, mcol = 0;
+    int SD = 0, col0 = 0, mcol = 0, xcol0 = -1;
     int have_fmax = 0;         // column mcol of every history row holds a bound on max_i delta_t[i]
 };
 
@@ -309,6 +309,7 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
         st.SD = vit::wave_hist_stride(plan->bp.wave_npl);
         st.col0 = st.SD - plan->S;
         st.mcol = 0;
+        st.xcol0 = 1;
         st.have_fmax = 1;
         e = vit::launch_wave(a, emis_dtype == VIT_F16, (hipStream_t)stream);
     } else if (family == 2) {
@@ -353,6 +354,7 @@ int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* len
     b.SD = st.SD;
     b.col0 = st.col0;
     b.mcol = st.mcol;
+    b.xcol0 = st.xcol0;
     b.W = plan->bp.ok ? plan->bp.W : 0;
     b.banded = plan->bp.ok ? 1 : 0;
     b.n_extras = plan->bp.ok ? plan->bp.n_extras : 0;
@@ -382,9 +384,9 @@ int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* len
     b.off_Arow = plan->L.off_Arow;
     b.off_rowc = plan->L.off_rowc;
     if (st.family == 3 && !(b.banded && b.n_dense == 0)) return VIT_EINVAL;   // (cannot happen: wave_ok implies both)
-    b.chunks = (b.bt_form == 0 && vit::sparse_backtrace_applies(b)) ? vit::sparse_backtrace_chunks(B, (int)T)
-                                                                     : vit::backtrace_chunks(B, (int)T);
-    b.warm = vit::kBtWarm;
+    const bool sparse = b.bt_form == 0 && vit::sparse_backtrace_applies(b);
+    b.chunks = sparse ? vit::sparse_backtrace_chunks(B, (int)T) : vit::backtrace_chunks(B, (int)T);
+    b.warm = sparse ? vit::kBtWarmSparse : vit::kBtWarm;
     // test hooks (vit_plan_set_option): force the chunking / warm-up so that the verify-and-repair pass is exercised
     if (tn.bt_chunks >= 1 && tn.bt_chunks <= vit::kBtMaxChunks) b.chunks = tn.bt_chunks;
     if (tn.bt_warm >= 0) b.warm = tn.bt_warm;

@@ -73,6 +73,7 @@ struct BtArgs {
     int64_t B;
     int T, S, SP, SD, W, K;
     int col0, mcol;         // history row layout: state i in column col0 + i, the frame maximum in column mcol
+    int xcol0;              // >= 0: column xcol0 + k holds a copy of delta of extra column k (next to the frame maximum); -1: none
     int chunks, warm;       // time-parallel back-trace: chunks per song, warm-up frames
     int banded;             // 1: row structure (window / c0 / extras / dense rows) proven by the plan
     int have_fmax;          // the forward pass was a banded kernel (it fills pad column S of the history rows)
@@ -91,7 +92,8 @@ hipError_t launch_dense(const FwdArgs& a, int songs_per_group, bool f16, hipStre
 hipError_t launch_step(const FwdArgs& a, bool f16, hipStream_t st);
 hipError_t launch_banded(const FwdArgs& a, bool f16, hipStream_t st);
 hipError_t launch_wave(const FwdArgs& a, bool f16, hipStream_t st);   // wave.hip: one song per wavefront
-// history layout of the wave form: row stride 64*npl floats, state i in column 64*npl - S + i, the frame maximum in column 0
+// history layout of the wave form: row stride 64*npl floats, state i in column 64*npl - S + i, the frame maximum in column 0,
+// a copy of delta of extra column k in column 1 + k
 constexpr int wave_hist_stride(int npl) { return 64 * npl; }
 hipError_t launch_backtrace(BtArgs a, hipStream_t st);
 // backtrace_sparse.hip: fetches only the span of each history row around the path (banded plans, candidates on one lane)
@@ -112,6 +114,7 @@ hipError_t launch_voicing_notes(const int32_t* states, int64_t n, int32_t n_bins
                                 int32_t* bins, float* notes, float* notes_v, hipStream_t st);
 int backtrace_tile_rows(int SD);
 constexpr int kBtWarm = 128;       // warm-up frames of a speculative chunk (survivor paths coalesce within tens of frames)
+constexpr int kBtWarmSparse = 64;  // the sparse kernel runs many short chunks: a shorter warm-up (a wrong guess only costs a repair)
 constexpr int kBtMaxChunks = 32;
 int backtrace_chunks(int64_t B, int T);
 

@@ -166,7 +166,8 @@ BandedPlan analyze_banded(const float* A, int S) {
         bp.wave_d = d;
         bp.wave_npl = (S + 63) / 64;
         bp.wave_dk = wave_table_d(bp.wave_npl, d);
-        bp.wave_ok = ok && bp.n_dense == 0 && bp.n_extras <= kWaveMaxExtras && bp.wave_dk > 0 && S < 64 * bp.wave_npl;
+        // (the idle leading slots of a history row carry the frame maximum and a copy of the extra columns' delta)
+        bp.wave_ok = ok && bp.n_dense == 0 && bp.n_extras <= kWaveMaxExtras && bp.wave_dk > 0 && S + bp.n_extras < 64 * bp.wave_npl;
     }
     bp.ok = true;
     return bp;

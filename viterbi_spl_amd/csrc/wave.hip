@@ -126,7 +126,7 @@ __device__ __forceinline__ void store_row(float* __restrict__ p, const float (&d
 // that, a lane's NPL emission columns are one unconditional vector load at E_row + NPL*lane - o -- for the leading
 // lanes that reaches back into the previous row of the SAME tensor (rows >= 1 only: row 0 is loaded element-wise), never
 // out of bounds -- and the history row is stored in slot order: row stride 64*NPL floats, state i in column o + i, and
-// M_t = max_i delta_t[i] in column 0 (an idle slot).  No branch surrounds a memory instruction, so the in-order vmcnt
+// M_t = max_i delta_t[i] in column 0, a copy of delta_t of extra column x in column 1 + x (idle slots).  No branch surrounds a memory instruction, so the in-order vmcnt
 // of the emission prefetch is exact.  The back-trace is told the column offset and the column of M (BtArgs::col0, mcol).
 template <int NPL, int D, int NX, int PF, int WPS, typename ET>
 __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
     constexpr int NG = 2 * H + 1;              // lane groups of the neighbourhood
     constexpr int NPM = wave_pairs(D);
     constexpr int SDW = 64 * NPL;              // history row stride of this form
-    static_assert(NPL <= 8 && NPL % 2 == 0 && NX <= kWaveMaxExtras && PF >= 1, "geometry (source pairs never straddle two lanes)");
+    static_assert(NPL <= 8 && NPL % 2 == 0 && NX <= kWaveMaxExtras && NX + 1 <= NPL && PF >= 1, "geometry (source pairs never straddle two lanes)");
     const int S = a.S, T = a.T;
     const int lane = threadIdx.x & 63;
     const int song = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -185,13 +185,26 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
         row = row < row_min ? row_min : row;
         RowIO<NPL, ET>::load(E + (size_t)row * S + ecol, e);
     };
-    // history row t in slot order; lane 0's first slot (always idle) carries M_t
-    auto store_hist = [&](const int t, const float (&d)[NPL], const float M) {
+    // history row t in slot order; lane 0's leading slots (always idle: o > NX is checked by the plan) carry M_t and a
+    // copy of delta_t of the extra columns, so that the sparse back-trace finds its per-row scalars in ONE cache line
+    auto store_hist = [&](const int t, const float (&d)[NPL], const float M, const float (&xd)[NX > 0 ? NX : 1]) {
         float v[NPL];
 #pragma unroll
         for (int k = 0; k < NPL; ++k) v[k] = d[k];
         v[0] = lane == 0 ? M : v[0];
+#pragma unroll
+        for (int x = 0; x < NX; ++x) v[1 + x] = lane == 0 ? xd[x] : v[1 + x];
         store_row<NPL>(hist + (size_t)t * SDW + NPL * lane, v);
+    };
+    // delta of the extra columns, wave-uniform
+    auto extra_deltas = [&](const float (&d)[NPL], float (&xd)[NX > 0 ? NX : 1]) {
+#pragma unroll
+        for (int x = 0; x < NX; ++x) {
+            float v = d[0];
+#pragma unroll
+            for (int k = 1; k < NPL; ++k) v = xs[x][k] ? d[k] : v;   // per-lane masks: one v_cndmask each
+            xd[x] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), xl[x]));
+        }
     };
 
     // ---------------- frame 0
@@ -211,7 +224,9 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
         return wave_max(loc);
     };
     float M = frame_max(d);
-    store_hist(0, d, M);
+    float xd[NX > 0 ? NX : 1] = {};
+    extra_deltas(d, xd);
+    store_hist(0, d, M, xd);
 
     float er[PF][NPL];
 #pragma unroll
@@ -222,15 +237,6 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
         for (int m = 0; m < NPM; ++m) asm volatile("" ::"v"(aw[k][m]));
 
     auto frame = [&](const int t, float (&e)[NPL]) {
-        // ---- extra columns: delta of state x, wave-uniform
-        float xd[NX > 0 ? NX : 1];
-#pragma unroll
-        for (int x = 0; x < NX; ++x) {
-            float v = d[0];
-#pragma unroll
-            for (int k = 1; k < NPL; ++k) v = xs[x][k] ? d[k] : v;   // per-lane masks: one v_cndmask each
-            xd[x] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), xl[x]));
-        }
         // ---- neighbourhood: group g holds delta of lane l - H + g
         float nb[NG][NPL];
 #pragma unroll
@@ -278,7 +284,8 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
             d[k] = m + e[k];
         }
         M = frame_max(d);
-        store_hist(t, d, M);
+        extra_deltas(d, xd);               // for the next frame's candidates, and for the history row
+        store_hist(t, d, M, xd);
         load_row(t + PF < Tb ? t + PF : Tb - 1, e);
     };
     int t = 1;
