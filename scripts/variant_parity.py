@@ -1,4 +1,4 @@
-"""Parity of a forward-kernel variant selected by VIT_DEBUG_FLAGS (argv[1]) against the CPU oracle (test infrastructure)."""
+"""Parity of a banded forward form (argv[1]: option forward_form, 1 .. 5) against the CPU oracle (test infrastructure)."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from viterbi_spl_amd import ViterbiDecoder, synth
@@ -6,7 +6,7 @@ from oracle import viterbi_oracle as vo
 dev = torch.device("cuda:0")
 logA_T, log_pi = synth.log_params(synth.tonet_transition(360, 14), synth.floored_prior(361))
 dec = ViterbiDecoder(logA_T, log_pi, dev)
-os.environ["VIT_DEBUG_FLAGS"] = sys.argv[1]
+dec.set_option("forward_form", int(sys.argv[1]))
 ok = True
 for (B, T, kind) in ((3, 400, "peaks"), (8, 2000, "ties"), (16, 5000, "dense"), (128, 3000, "peaks")):
     gen = {"peaks": synth.emissions_peaks, "ties": synth.emissions_ties, "dense": synth.emissions_dense}[kind]
