@@ -158,37 +158,6 @@ def oracle_spot_check(logA_T, log_pi, E, states, loglik, songs):
     return bool(np.array_equal(states[songs].cpu().numpy(), rs)) and bool(np.array_equal(loglik[songs].cpu().numpy(), rl))
 
 
-def two_batches_in_flight(dec, E, algo, steps):
-    """Throughput when TWO independent [B,T,S] batches are in flight: the forward passes of consecutive steps run on two
-    streams (a batch of 128 one-song workgroups occupies half of the chip's 256 CUs), each followed by its back-trace.
-    Every step still decodes its own complete batch; three workspace / path-buffer slots."""
-    B, T, _ = E.shape
-    dev = E.device
-    n_slot = 3
-    st = [torch.empty((B, T), dtype=torch.int32, device=dev) for _ in range(n_slot)]
-    ll = [torch.empty((B,), dtype=torch.float32, device=dev) for _ in range(n_slot)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
-    done = [None] * n_slot
-
-    def run(n):
-        for i in range(n):
-            k, sq = i % n_slot, streams[i % 2]
-            with torch.cuda.stream(sq):
-                if done[k] is not None:
-                    sq.wait_event(done[k])
-                dec.decode_into(E, st[k], ll[k], algo=algo, slot=10 + k)
-                done[k] = torch.cuda.Event()
-                done[k].record()
-        torch.cuda.synchronize()
-
-    run(n_slot)
-    t0 = time.perf_counter()
-    run(steps)
-    wall = time.perf_counter() - t0
-    return {"steps": steps, "wall_ms_per_step": wall / steps * 1e3, "Mframes_per_s": B * T * steps / wall / 1e6,
-            "note": "two independent batches in flight on two streams; each step decodes its own complete batch"}, st[(steps - 1) % n_slot], ll[(steps - 1) % n_slot]
-
-
 def extra_blocks(dev, args):
     """The saturation sweep and the high-resolution configuration, measured in this process after the headline."""
     out = {}
@@ -398,13 +367,6 @@ def main():
             if not args.serial:        # the same steps without the overlap, for the record
                 ser, _, _ = time_serial(dec, E, algo, steps=3)
                 out["serial_schedule"] = {**ser, "Mframes_per_s": B * T / ser["wall_ms_per_step"] / 1e3}
-                if B <= 128:           # half of the chip is idle during a forward pass: what two batches in flight deliver
-                    tb, st2, ll2 = two_batches_in_flight(dec, E, algo, steps=6)
-                    tb["same_result"] = bool(torch.equal(st2, states) and torch.equal(ll2, loglik))
-                    out["two_batches_in_flight"] = tb
-                    del st2, ll2
-                    for k in range(3):
-                        dec._ws_slots.pop(10 + k, None)
             if not args.no_cpu_baseline:
                 cb, cbc = cpu_baseline(logA_T, log_pi, E, states, loglik, args.cpu_seconds)
                 out["cpu_baseline"] = cb
