@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--dmax", type=int, default=14, help="band half-width of the tonet-recipe transition (tonet 14, jdc 40, imm 56)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the sweep / configs4 blocks")
+    ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes (roofline.traffic from profiles/traffic.json)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--serial", action="store_true", help="one stream: no overlap between consecutive steps")
     ap.add_argument("--option", action="append", default=[], help="vit_plan_set_option key=value (kernel-selection override)")
@@ -141,6 +142,50 @@ def cpu_baseline(logA_T, log_pi, E, gpu_states, gpu_loglik, seconds):
              "sample": f"{nb} songs, T={T}, scalar C restatement, one song per thread (oracle/viterbi_oracle.c)",
              "bit_exact_vs_gpu": exact_c}
     return out, out_c
+
+
+def measure_traffic(B, T, algo, options):
+    """HBM bytes per launch of the forward and back-trace kernels from the PMC counters, collected in this run: two
+    rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE: they do not fit one pass, and no tracing domain is combined
+    with them) over a child process that decodes the same [B, T, 361] tonet batch twice (scripts/prof_target.py; songs
+    repeat with period 32).  gfx950: FETCH_SIZE counts 64 B per 128-byte request of a wide coalesced stream, so read
+    bytes = 2 x FETCH_SIZE x 1024 (MI355X_MICROARCH.md, HBM); WRITE_SIZE x 1024 is exact.  Returns None if rocprofv3 is not
+    available or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    tmp = tempfile.mkdtemp(prefix="vit_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    sums = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, counter), "--",
+                   sys.executable, os.path.join(ROOT, "scripts", "prof_target.py"), str(B), algo, "2", str(T)] + list(options)
+            r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=420)
+            if r.returncode != 0:
+                return None
+            for f in glob.glob(os.path.join(tmp, counter, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    k = row["Kernel_Name"]
+                    if "vit::" in k and row["Counter_Name"] == counter:
+                        name = k.split("vit::")[1].split("<")[0].split("(")[0]
+                        sums.setdefault((name, counter), []).append(float(row["Counter_Value"]))
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    launches = 2
+    out = {}
+    for (name, counter), vals in sums.items():
+        out.setdefault(name, {})[counter + "_KiB_per_launch"] = sum(vals) / launches      # (the verify pass is its own dispatch: summed)
+    for name, d in out.items():
+        d["hbm_bytes_per_launch"] = int(2 * d.get("FETCH_SIZE_KiB_per_launch", 0.0) * 1024 + d.get("WRITE_SIZE_KiB_per_launch", 0.0) * 1024)
+    return out or None
 
 
 def tiled_emissions(gen, B, T, S, seed, dev, dtype, period=32):
@@ -364,6 +409,17 @@ def main():
         }
         if world == 1 and not use_dist:
             torch.cuda.synchronize()
+            if not args.no_traffic and (S, args.transition, args.dmax, args.f16, args.emissions) == (361, "tonet", 14, False, "peaks"):
+                pm = measure_traffic(B, T, algo, args.option)
+                if pm and fwd_kernel in pm:
+                    bt_names = [k for k in pm if "backtrace" in k]
+                    out["roofline"]["traffic"] = pm[fwd_kernel]["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate, no tracing "
+                                                        "domains) over scripts/prof_target.py decoding the same batch shape twice; read bytes = 2 x FETCH_SIZE x 1024 "
+                                                        "(gfx950: 64 B counted per 128-byte request), write bytes = WRITE_SIZE x 1024")
+                    out["roofline"]["traffic_over_algorithmic"] = pm[fwd_kernel]["hbm_bytes_per_launch"] / fwd_bytes
+                    out["backtrace"]["traffic"] = sum(pm[k]["hbm_bytes_per_launch"] for k in bt_names) if bt_names else None
+                    out["pmc"] = pm
             if not args.serial:        # the same steps without the overlap, for the record
                 ser, _, _ = time_serial(dec, E, algo, steps=3)
                 out["serial_schedule"] = {**ser, "Mframes_per_s": B * T / ser["wall_ms_per_step"] / 1e3}
