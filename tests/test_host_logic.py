@@ -72,6 +72,8 @@ def test_adapters_keep_reference_assertions(golden):
     bad[0, 0] += 0.5
     with pytest.raises(AssertionError):
         ra.viterbi_librosa_c_fn(transition_matrix=bad, prob_init=pi, probs_st=P)
+    with pytest.raises(AssertionError):      # float64 parameters: not the arithmetic this library reproduces
+        ra.viterbi_librosa_c_fn(transition_matrix=A.astype(np.float64), prob_init=pi, probs_st=P)
     with pytest.raises(AssertionError):
         ra.viterbi_librosa_fn(log_transition_matrix_T=np.asfortranarray(A), log_prob_init=pi, log_probs_st=P)
     with pytest.raises(AssertionError):

@@ -47,6 +47,10 @@ def viterbi_librosa_fn(*, log_transition_matrix_T, log_prob_init, log_probs_st):
 
 # ----------------------------------------------------------------------------- family A
 def _check_probs(transition_matrix, prob_init, probs_st):
+    # float32 inputs only: with float64 parameters the reference's NumPy code (dcnet/tf_viterbi_decoding.py:183-197) adds a
+    # float32 delta to float64 log-probabilities and rounds once, which float32 kernels do not reproduce; the compiled core it
+    # replaces takes f4 arrays only ('i8[:](f4[:, ::1], f4[:], f4[:, ::1])', dcnet/aot_viterbi_core.py:8)
+    assert transition_matrix.dtype == np.float32 and np.asarray(prob_init).dtype == np.float32 and probs_st.dtype == np.float32
     S = len(transition_matrix)
     assert transition_matrix.shape == (S, S)
     assert probs_st.shape[0] == S and probs_st.ndim == 2
