@@ -7,6 +7,6 @@ __version__ = "0.2.0"
 
 from .decoder import ViterbiDecoder, decode, get_decoder  # noqa: F401
 from .reference_api import (  # noqa: F401
-    RecordingAccumulator, ScaledSoftMaxViterbi, SoftMaxViterbi, Viterbi, viterbi_librosa_c_fn, viterbi_librosa_fn,
-    viterbi_numba_core, viterbi_numba_fn,
+    RecordingAccumulator, ScaledSoftMaxViterbi, SoftMaxViterbi, Viterbi, tf_viterbi_librosa_fn, viterbi_librosa_c_fn,
+    viterbi_librosa_fn, viterbi_numba_core, viterbi_numba_fn, viterbi_tf_fn,
 )

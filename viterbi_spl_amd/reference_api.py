@@ -11,6 +11,8 @@ last bit a GPU cannot be trusted to reproduce.
   family D  viterbi_librosa_fn(*, log_transition_matrix_T, log_prob_init, log_probs_st)
             imm/tf_viterbi.py:75-109
   AOT core  viterbi_numba_core(B, prob_init, probs)   dcnet/aot_viterbi_core.py:8-54
+  TF graph  viterbi_tf_fn(transition_matrix, prob_init, probs_st) -> int32        dcnet/tf_viterbi_decoding.py:23-72
+  TF eager  tf_viterbi_librosa_fn(*, tf_log_transition_matrix_T, ...) -> int32    imm/tf_viterbi.py:8-72
   family B  Viterbi.viterbi_librosa_fn(self, probs_st)          tonet/for_paper.py:1833-1870
   family C  SoftMaxViterbi.viterbi_librosa_fn(self, probs_ts)   tonet/for_paper.py:1999-2037
 """
@@ -91,6 +93,38 @@ def viterbi_numba_core(B, prob_init, probs):
     prob_init[:] = np.log(prob_init + tinyp)
     probs[:] = np.log(probs + tinyp)
     return _run(B, prob_init, probs)
+
+
+# ----------------------------------------------------------------------------- the TensorFlow variants (rows a3 / a7)
+def _to_numpy(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy()
+    return x.numpy() if hasattr(x, 'numpy') else np.asarray(x)       # tf.Tensor / tf.Variable expose .numpy() as well
+
+
+def viterbi_tf_fn(transition_matrix, prob_init, probs_st):
+    """Call surface of the TF-graph variant (dcnet/tf_viterbi_decoding.py:23-72): positional probabilities in (tensors or
+    arrays, converted to float32 as ``tf.convert_to_tensor(..., tf.float32)`` does), S hard-wired to 321 there, the
+    ``tf.debugging.assert_near`` checks on the row sums, ``int32[T]`` states out.  Same float32 recursion as family A; the
+    log is NumPy's here (TensorFlow's own log may differ in the last bit: that variant's outputs are parity unpinned)."""
+    A = np.asarray(_to_numpy(transition_matrix), np.float32)
+    pi = np.asarray(_to_numpy(prob_init), np.float32)
+    P = np.asarray(_to_numpy(probs_st), np.float32)
+    assert np.allclose(np.sum(A, axis=1), 1., atol=1e-6 * A.shape[1]) and np.isclose(np.sum(pi), 1., atol=1e-5)
+    return viterbi_librosa_c_fn(transition_matrix=A, prob_init=pi, probs_st=np.asfortranarray(P)).astype(np.int32)
+
+
+def tf_viterbi_librosa_fn(*, tf_log_transition_matrix_T, tf_log_prob_init, tf_or_np_log_probs_st):
+    """Call surface of the TF-eager log-domain variant (imm/tf_viterbi.py:8-72): ``[S,S]`` target <- source log-matrix,
+    ``[S]`` log-prior, ``[S,T]`` log-emissions (tensor or array, taken as float32), ``int32[T]`` states out."""
+    B = np.require(_to_numpy(tf_log_transition_matrix_T), np.float32, ['C'])
+    prob_init = np.asarray(_to_numpy(tf_log_prob_init), np.float32)
+    probs = np.asarray(_to_numpy(tf_or_np_log_probs_st), np.float32)
+    S = len(B)
+    assert B.shape == (S, S)
+    assert len(prob_init) == S
+    assert probs.shape == (S, probs.shape[1])
+    return viterbi_librosa_fn(log_transition_matrix_T=B, log_prob_init=prob_init, log_probs_st=probs).astype(np.int32)
 
 
 # ----------------------------------------------------------------------------- families B / C
