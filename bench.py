@@ -166,7 +166,7 @@ def measure_traffic(B, T, algo, options):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, counter), "--",
                    sys.executable, os.path.join(ROOT, "scripts", "prof_target.py"), str(B), algo, "2", str(T)] + list(options)
-            r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=420)
+            r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=150)
             if r.returncode != 0:
                 return None
             for f in glob.glob(os.path.join(tmp, counter, "**", "*counter_collection.csv"), recursive=True):
