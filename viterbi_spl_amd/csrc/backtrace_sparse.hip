@@ -4,8 +4,8 @@
 // is HBM-bound doing so (5.5 TB/s; 21 % of a step at B = 1024).  The path moves slowly -- a band transition moves it by
 // at most the band half-width, and in music it moves by a bin or two per frame -- so this kernel fetches, for a tile of
 // K frames, only
-//   * the SPAN: NS consecutive columns around the window of the current path state (NS = 64: the W-wide window plus a
-//     guard on either side), the same columns for every row of the tile, and
+//   * the SPAN: NS consecutive columns around the window of the current path state (NS = 64 for windows up to 32 wide,
+//     128 up to 96: the window plus a guard of at least 16 columns on either side), the same columns for every row, and
 //   * the row's auxiliary values: the frame maximum (column mcol) and delta of the extra columns,
 // i.e. 3-5 cache lines of a row's 12.  Per frame t (descending) the decision is the one banded_backtrace_kernel takes:
 // candidates fl(delta_t[i] + logA_T[j][i]) over the window and the extra columns of the path state j at t+1, wave max,
@@ -27,10 +27,9 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kSpK = 16;            // rows per tile
-constexpr int kSpNS = 64;           // span columns per row (multiple of 4)
 constexpr int kSpAux = 8;           // auxiliary floats per row: [0] frame maximum, [1 + k] extra column k
-constexpr int kSpRS = kSpNS + kSpAux;   // floats per tile row
-constexpr int kSpVec = kSpK * kSpNS / 4 / 64;   // float4 per lane per tile
+// span columns per row (multiple of 4): the window plus at least 16 columns of guard on either side
+constexpr int sp_span(int kc) { return kc == 1 ? 64 : 128; }
 
 __device__ __forceinline__ int sp_song_length(const int64_t* lengths, int song, int T) {
     if (!lengths) return T;
@@ -61,10 +60,16 @@ __device__ __forceinline__ float sp_wave_max(float x) {   // kernels.hip wave_ma
 
 // NWT: 64 * NWT >= S (sources per lane in the full evaluation).  AFF: window start affine in the target.
 // MODE 0: speculative pass, one wave per (song, chunk).  MODE 1: verify-and-repair pass, one wave per song.
-template <int NWT, bool AFF, int MODE>
+// KC: candidate slots per lane (slot k of lane l holds candidate 64k + l: the W window entries, then the extra columns, then
+// the bound): 1 for windows up to 59 wide, 2 up to 123 (the jdc band on the 722-state grid: W = 96).  GT: the per-target
+// candidate table is read from the plan image (L2) instead of LDS -- at S = 722, W = 96 it is 310 KB.
+template <int NWT, bool AFF, int MODE, int KC, bool GT>
 __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int EPL = NWT;
+    constexpr int kSpNS = sp_span(KC);
+    constexpr int kSpRS = kSpNS + kSpAux;             // floats per tile row
+    constexpr int kSpVec = kSpK * kSpNS / 4 / 64;     // float4 per lane per tile
     const int S = a.S, SP = a.SP, SD = a.SD, T = a.T, W = a.W;
     const int nx = a.n_extras;
     const int WX1 = W + kMaxExtras + 1;    // candidate-table row: window, extras, row constant
@@ -72,15 +77,16 @@ __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
     const int nwaves = blockDim.x >> 6;
     float* tiles = reinterpret_cast<float*>(smem);                          // [nwaves][kSpK * kSpRS]
     int32_t* loL = reinterpret_cast<int32_t*>(tiles + nwaves * kSpK * kSpRS);   // [SP]
-    float* tabX = reinterpret_cast<float*>(loL + SP);                       // [SP][WX1]
+    float* tabX = reinterpret_cast<float*>(loL + SP);                       // [SP][WX1] (LDS form only)
+    const float* __restrict__ gtab = reinterpret_cast<const float*>(a.image + a.off_tabX);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     {
         const int32_t* gl = reinterpret_cast<const int32_t*>(a.image + a.off_lo);
-        const float* __restrict__ gtab = reinterpret_cast<const float*>(a.image + a.off_tabX);
         const int nthr = blockDim.x;
         for (int k = tid; k < SP; k += nthr) loL[k] = gl[k];
-        for (int k = tid; k < SP * WX1; k += nthr) tabX[k] = gtab[k];
+        if (!GT)
+            for (int k = tid; k < SP * WX1; k += nthr) tabX[k] = gtab[k];
     }
     __syncthreads();
 
@@ -94,14 +100,22 @@ __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
     const float* __restrict__ hist = a.hist + (size_t)song * T * SD;
     float* tile = tiles + wv * kSpK * kSpRS;
 
-    // ---- per-lane constants: lane l < W window candidate l, lanes W .. W+nx-1 the extra columns, lane CB the bound
-    const bool isw = lane < W;
-    const bool isx = lane >= W && lane < W + nx;
-    const bool cand = lane < W + nx;
-    const int xs = isx ? a.extras[(lane - W) & (kMaxExtras - 1)] : 0;      // state of the extra-column candidate
-    const int auxi = lane == CB ? 0 : 1 + ((lane - W) & (kMaxExtras - 1));  // aux entry read by a non-window lane
-    const int tb = lane < WX1 ? lane : WX1 - 1;
-    const unsigned long long wmask = W >= 64 ? ~0ull : ((1ull << W) - 1ull);
+    // ---- per-lane constants, per candidate slot: candidates 0 .. W-1 the window, W .. W+nx-1 the extra columns, CB the bound
+    bool isw[KC], cand[KC];
+    int xs[KC], auxi[KC], tb[KC];
+    unsigned long long wmask[KC];                                          // lanes of slot k that hold window candidates
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        const int c = 64 * k + lane;
+        isw[k] = c < W;
+        cand[k] = c < W + nx;
+        xs[k] = (c >= W && c < W + nx) ? a.extras[(c - W) & (kMaxExtras - 1)] : 0;     // state of an extra-column candidate
+        auxi[k] = c == CB ? 0 : 1 + ((c - W) & (kMaxExtras - 1));                      // aux entry read by a non-window candidate
+        tb[k] = c < WX1 ? c : WX1 - 1;
+        const int nwin = W - 64 * k;
+        wmask[k] = nwin >= 64 ? ~0ull : (nwin <= 0 ? 0ull : ((1ull << nwin) - 1ull));
+    }
+    const int kb = CB >> 6, lb = CB & 63;                                  // slot / lane of the bound candidate
     // aux loads: entry e of row r by lane r * 8 + e (two halves of eight rows)
     const int aux_e = lane & 7;
     const int aux_col = aux_e == 0 ? a.mcol : (aux_e <= nx ? (a.xcol0 >= 0 ? a.xcol0 + aux_e - 1 : a.col0 + a.extras[(aux_e - 1) & (kMaxExtras - 1)]) : a.mcol);
@@ -168,22 +182,45 @@ __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
                 const int wlo = a.col0 + lo - c0;                       // window start inside the span
                 if (wlo < 0 || wlo + W > kSpNS) { rmiss = r; break; }
                 const float* trow = tile + r * kSpRS;
-                const float dv = trow[isw ? wlo + lane : kSpNS + auxi];
-                const float av = tabX[cur * WX1 + tb];
-                float v = dv + av;
-                const float mf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), CB));   // fl(M_t + c_cur)
-                const float cj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(av), CB));
-                v = cand ? v : -INFINITY;
-                const float m = sp_wave_max(v);
+                float v[KC], av[KC];
+#pragma unroll
+                for (int k = 0; k < KC; ++k) {
+                    const float dv = trow[isw[k] ? wlo + 64 * k + lane : kSpNS + auxi[k]];
+                    av[k] = GT ? gtab[(size_t)cur * WX1 + tb[k]] : tabX[cur * WX1 + tb[k]];
+                    v[k] = dv + av[k];
+                }
+                float mf = 0.f, cj = 0.f;                              // fl(M_t + c_cur) and c_cur, from the bound candidate
+#pragma unroll
+                for (int k = 0; k < KC; ++k)
+                    if (KC == 1 || k == kb) {
+                        mf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), lb));
+                        cj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(av[k]), lb));
+                    }
+                float mloc = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < KC; ++k) {
+                    v[k] = cand[k] ? v[k] : -INFINITY;
+                    mloc = fmaxf(mloc, v[k]);
+                }
+                const float m = sp_wave_max(mloc);
                 auto lowest_candidate = [&](const float mm) -> unsigned {
                     unsigned best = 0x7fffffffu;
-                    const unsigned long long mk = __ballot(v == mm && cand);
-                    if (mk & wmask) best = lo + __builtin_ctzll(mk & wmask);     // window candidates ascend with the source
-                    unsigned long long mx = mk & ~wmask;                        // extra columns: arbitrary indices
-                    while (mx) {
-                        const unsigned c = __builtin_amdgcn_readlane(xs, __builtin_ctzll(mx));
-                        best = c < best ? c : best;
-                        mx &= mx - 1;
+                    bool have_w = false;
+#pragma unroll
+                    for (int k = 0; k < KC; ++k) {
+                        const unsigned long long mk = __ballot(v[k] == mm && cand[k]);
+                        const unsigned long long mw = mk & wmask[k];
+                        if (mw && !have_w) {                                 // window candidates ascend with the source index
+                            const unsigned c = lo + 64 * k + __builtin_ctzll(mw);
+                            best = c < best ? c : best;
+                            have_w = true;
+                        }
+                        unsigned long long mx = mk & ~wmask[k];              // extra columns: arbitrary indices
+                        while (mx) {
+                            const unsigned c = __builtin_amdgcn_readlane(xs[k], __builtin_ctzll(mx));
+                            best = c < best ? c : best;
+                            mx &= mx - 1;
+                        }
                     }
                     return best;
                 };
@@ -279,33 +316,45 @@ __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
     }
 }
 
-size_t sparse_backtrace_lds(const BtArgs& a, int nwaves) {
-    return sizeof(float) * ((size_t)nwaves * kSpK * kSpRS + (size_t)a.SP * (a.W + kMaxExtras + 1)) + sizeof(int32_t) * a.SP;
+static int sparse_kc(const BtArgs& a) { return (a.W + kMaxExtras + 1 + 63) / 64; }
+
+// LDS bytes: tiles + window starts (+ the candidate table when it fits next to at least four waves' tiles)
+static size_t sparse_lds_bytes(const BtArgs& a, int nwaves, bool table_in_lds) {
+    const int rs = sp_span(sparse_kc(a)) + kSpAux;
+    return sizeof(float) * ((size_t)nwaves * kSpK * rs + (table_in_lds ? (size_t)a.SP * (a.W + kMaxExtras + 1) : 0)) + sizeof(int32_t) * a.SP;
 }
+static bool sparse_table_fits(const BtArgs& a) { return sparse_lds_bytes(a, 4, true) + 1024 <= 160 * 1024; }
 
 // The sparse kernel takes banded plans without dense rows whose forward pass left the frame maximum in the history,
-// with every candidate on one lane and the span inside a row.
+// with at most two candidates per lane and the span inside a row.
 bool sparse_backtrace_applies(const BtArgs& a) {
-    return a.banded && a.have_fmax && a.n_dense == 0 && a.W + kMaxExtras + 1 <= 64 && a.W + 8 <= kSpNS && a.SD >= kSpNS &&
-           a.SD % 4 == 0 && (a.S + 63) / 64 <= 12 && sparse_backtrace_lds(a, 4) + 1024 <= 160 * 1024;
+    const int kc = sparse_kc(a);
+    return a.banded && a.have_fmax && a.n_dense == 0 && kc <= 2 && a.W + 32 <= sp_span(kc) && a.SD >= sp_span(kc) &&
+           a.SD % 4 == 0 && (a.S + 63) / 64 <= 12;
 }
 
-template <int NWT, bool AFF>
+template <int NWT, bool AFF, int KC, bool GT>
 static hipError_t launch_sparse_t(const BtArgs& a, hipStream_t st) {
     int nw = 16;
-    while (nw > 4 && sparse_backtrace_lds(a, nw) + 1024 > 160 * 1024) nw >>= 1;
-    const size_t lds = sparse_backtrace_lds(a, nw);
+    while (nw > 4 && sparse_lds_bytes(a, nw, !GT) + 1024 > 160 * 1024) nw >>= 1;
+    const size_t lds = sparse_lds_bytes(a, nw, !GT);
     const long long waves0 = (long long)a.B * a.chunks;
-    hipLaunchKernelGGL((sparse_backtrace_kernel<NWT, AFF, 0>), dim3((int)((waves0 + nw - 1) / nw)), dim3(nw * 64), lds, st, a);
+    hipLaunchKernelGGL((sparse_backtrace_kernel<NWT, AFF, 0, KC, GT>), dim3((int)((waves0 + nw - 1) / nw)), dim3(nw * 64), lds, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || a.chunks <= 1) return e;
-    hipLaunchKernelGGL((sparse_backtrace_kernel<NWT, AFF, 1>), dim3((int)((a.B + nw - 1) / nw)), dim3(nw * 64), lds, st, a);
+    hipLaunchKernelGGL((sparse_backtrace_kernel<NWT, AFF, 1, KC, GT>), dim3((int)((a.B + nw - 1) / nw)), dim3(nw * 64), lds, st, a);
     return hipGetLastError();
 }
 
 template <int NWT>
 static hipError_t launch_sparse_a(const BtArgs& a, hipStream_t st) {
-    return a.lo_affine ? launch_sparse_t<NWT, true>(a, st) : launch_sparse_t<NWT, false>(a, st);
+    const bool gt = !sparse_table_fits(a);
+    if (sparse_kc(a) == 1) {
+        if (gt) return a.lo_affine ? launch_sparse_t<NWT, true, 1, true>(a, st) : launch_sparse_t<NWT, false, 1, true>(a, st);
+        return a.lo_affine ? launch_sparse_t<NWT, true, 1, false>(a, st) : launch_sparse_t<NWT, false, 1, false>(a, st);
+    }
+    if (gt) return a.lo_affine ? launch_sparse_t<NWT, true, 2, true>(a, st) : launch_sparse_t<NWT, false, 2, true>(a, st);
+    return a.lo_affine ? launch_sparse_t<NWT, true, 2, false>(a, st) : launch_sparse_t<NWT, false, 2, false>(a, st);
 }
 
 hipError_t launch_backtrace_sparse(const BtArgs& a, hipStream_t st) {
