@@ -29,7 +29,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kSpK = 16;            // rows per tile
 constexpr int kSpAux = 8;           // auxiliary floats per row: [0] frame maximum, [1 + k] extra column k
 // span columns per row (multiple of 4): the window plus at least 16 columns of guard on either side
-constexpr int sp_span(int kc) { return kc == 1 ? 64 : 128; }
+constexpr int sp_span(int kc) { return kc == 1 ? 64 : (kc == 2 ? 128 : 160); }
 
 __device__ __forceinline__ int sp_song_length(const int64_t* lengths, int song, int T) {
     if (!lengths) return T;
@@ -61,7 +61,7 @@ __device__ __forceinline__ float sp_wave_max(float x) {   // kernels.hip wave_ma
 // NWT: 64 * NWT >= S (sources per lane in the full evaluation).  AFF: window start affine in the target.
 // MODE 0: speculative pass, one wave per (song, chunk).  MODE 1: verify-and-repair pass, one wave per song.
 // KC: candidate slots per lane (slot k of lane l holds candidate 64k + l: the W window entries, then the extra columns, then
-// the bound): 1 for windows up to 59 wide, 2 up to 123 (the jdc band on the 722-state grid: W = 96).  GT: the per-target
+// the bound): 1 for windows up to 59 wide, 2 up to 123 (the jdc band on the 722-state grid: W = 96), 3 for W = 128 (imm).  GT: the per-target
 // candidate table is read from the plan image (L2) instead of LDS -- at S = 722, W = 96 it is 310 KB.
 template <int NWT, bool AFF, int MODE, int KC, bool GT>
 __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
@@ -326,10 +326,10 @@ static size_t sparse_lds_bytes(const BtArgs& a, int nwaves, bool table_in_lds) {
 static bool sparse_table_fits(const BtArgs& a) { return sparse_lds_bytes(a, 4, true) + 1024 <= 160 * 1024; }
 
 // The sparse kernel takes banded plans without dense rows whose forward pass left the frame maximum in the history,
-// with at most two candidates per lane and the span inside a row.
+// with at most three candidates per lane and the span inside a row.
 bool sparse_backtrace_applies(const BtArgs& a) {
     const int kc = sparse_kc(a);
-    return a.banded && a.have_fmax && a.n_dense == 0 && kc <= 2 && a.W + 32 <= sp_span(kc) && a.SD >= sp_span(kc) &&
+    return a.banded && a.have_fmax && a.n_dense == 0 && kc <= 3 && a.W + 32 <= sp_span(kc) && a.SD >= sp_span(kc) &&
            a.SD % 4 == 0 && (a.S + 63) / 64 <= 12;
 }
 
@@ -353,8 +353,12 @@ static hipError_t launch_sparse_a(const BtArgs& a, hipStream_t st) {
         if (gt) return a.lo_affine ? launch_sparse_t<NWT, true, 1, true>(a, st) : launch_sparse_t<NWT, false, 1, true>(a, st);
         return a.lo_affine ? launch_sparse_t<NWT, true, 1, false>(a, st) : launch_sparse_t<NWT, false, 1, false>(a, st);
     }
-    if (gt) return a.lo_affine ? launch_sparse_t<NWT, true, 2, true>(a, st) : launch_sparse_t<NWT, false, 2, true>(a, st);
-    return a.lo_affine ? launch_sparse_t<NWT, true, 2, false>(a, st) : launch_sparse_t<NWT, false, 2, false>(a, st);
+    if (sparse_kc(a) == 2) {
+        if (gt) return a.lo_affine ? launch_sparse_t<NWT, true, 2, true>(a, st) : launch_sparse_t<NWT, false, 2, true>(a, st);
+        return a.lo_affine ? launch_sparse_t<NWT, true, 2, false>(a, st) : launch_sparse_t<NWT, false, 2, false>(a, st);
+    }
+    if (gt) return a.lo_affine ? launch_sparse_t<NWT, true, 3, true>(a, st) : launch_sparse_t<NWT, false, 3, true>(a, st);
+    return a.lo_affine ? launch_sparse_t<NWT, true, 3, false>(a, st) : launch_sparse_t<NWT, false, 3, false>(a, st);
 }
 
 hipError_t launch_backtrace_sparse(const BtArgs& a, hipStream_t st) {
