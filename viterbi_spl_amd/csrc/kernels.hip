@@ -404,8 +404,10 @@ __global__ void __launch_bounds__(256) step4_forward_kernel(FwdArgs a) {
     constexpr int PAD = KB * BW + BW;             // -inf margin on both sides of every V_k (multiple of 4)
     constexpr int VLEN = NPV + 2 * PAD;
     constexpr int DLEN = NPV + 64;
+    constexpr int FLEN = VLEN / 4;                // quads per V_k (PAD and NPV are multiples of 4)
     float* V = reinterpret_cast<float*>(smem);    // [2][KB][VLEN]
-    float* dl = V + 2 * KB * VLEN;                // [2][DLEN]  delta of the voiced states (for the unvoiced target's row)
+    float* F = V + 2 * KB * VLEN;                 // [2][KB][FLEN]  F_k[u] = max of the quad V_k[4u .. 4u+3]
+    float* dl = F + 2 * KB * FLEN;                // [2][DLEN]  delta of the voiced states (for the unvoiced target's row)
     float* wm = dl + 2 * DLEN;                    // [2][4]     wave maxima of V_KB, slot 3 = the unvoiced source's candidate
     float* dun = wm + 2 * 4;                      // [2]        delta of the unvoiced state
     VI* tot = reinterpret_cast<VI*>(dun + 2 + 2);
@@ -421,7 +423,7 @@ __global__ void __launch_bounds__(256) step4_forward_kernel(FwdArgs a) {
     float* __restrict__ hist = a.hist + (size_t)song * T * SD;
     const float* __restrict__ lpi = reinterpret_cast<const float*>(a.image + a.off_logpi);
 
-    for (int k = tid; k < 2 * KB * VLEN + 2 * DLEN + 2 * 4 + 4; k += 256) V[k] = -INFINITY;
+    for (int k = tid; k < 2 * KB * VLEN + 2 * KB * FLEN + 2 * DLEN + 2 * 4 + 4; k += 256) V[k] = -INFINITY;
     __syncthreads();
 
     const bool voiced_wave = wv < NW4;
@@ -488,12 +490,29 @@ __global__ void __launch_bounds__(256) step4_forward_kernel(FwdArgs a) {
 
     auto mx3 = [](float acc, float x, float y) { return fmaxf(fmaxf(acc, x), y); };
 
+#ifdef VIT_TIMING_HOOKS
+    const bool prof = (a.debug & 256) != 0;      // phase stamps: publish | barrier | consume | store + prefetch -> scratch[song][4*wave ..]
+#else
+    constexpr bool prof = false;
+#endif
+    unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0;
+    auto stamp = [&]() -> unsigned long long {
+        unsigned long long v;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");
+        return v;
+    };
     auto frame = [&](const int t, f32x4& e_slot, const int b) {
+        const unsigned long long s0 = prof ? stamp() : 0ull;
         // ---- publish delta_{t-1} into buffer b
         if (voiced_wave) {
             float* vb = V + b * KB * VLEN + PAD + j0;
+            float* fb = F + b * KB * FLEN + PAD / 4 + tid;
 #pragma unroll
-            for (int k = 0; k < KB; ++k) *reinterpret_cast<f32x4*>(vb + k * VLEN) = dn + c[k];
+            for (int k = 0; k < KB; ++k) {
+                const f32x4 vq = dn + c[k];
+                *reinterpret_cast<f32x4*>(vb + k * VLEN) = vq;
+                fb[k * FLEN] = fmaxf(fmaxf(fmaxf(vq.x, vq.y), vq.z), vq.w);
+            }
             *reinterpret_cast<f32x4*>(dl + b * DLEN + j0) = dn;
             const f32x4 vf = dn + c[KB];
             const float inc = wave_scan_max(fmaxf(fmaxf(vf.x, vf.y), fmaxf(vf.z, vf.w)));
@@ -502,65 +521,70 @@ __global__ void __launch_bounds__(256) step4_forward_kernel(FwdArgs a) {
             dun[b] = dn.x;
             wm[b * 4 + 3] = dn.x + cn;
         }
+        const unsigned long long s1 = prof ? stamp() : 0ull;
         __syncthreads();
+        const unsigned long long s2 = prof ? stamp() : 0ull;
         // ---- consume
         f32x4 m = ninf4;
         if (voiced_wave) {
             const float* rb = V + b * KB * VLEN + PAD + j0;                 // 16-byte aligned; offsets below are relative to state j0
-            // band 0: target q takes offsets q-19 .. q+19; read -20 .. 23 (11 float4), shared core -16 .. 19
-            {
-                float x[44];
+            const float* fr = F + b * KB * FLEN + PAD / 4 + tid;          // own quad's slot in F_0
+            // A stage is one 24-source read window (six quads Q0 .. Q5 from a 16-byte aligned base): the four targets share the
+            // four inner quads whole, so those arrive as their published maxima F (four floats) and only Q0 and Q5 are read in
+            // full -- 2 ds_read_b128 + 4 ds_read_b32 and ~9 max operations per stage instead of 6 ds_read_b128 and ~19.
+            // Stage 0, 1: band 0 (left-type window ending at the target, right-type window starting at it; the target's own
+            // source is in both, which a maximum does not mind); stage 2k, 2k+1: band k right, left.
+            // One wave per SIMD: nothing else covers the LDS latency, so the reads run LA stages ahead of the maxima.
+            constexpr int LA = 3;                                         // stages in flight ahead of the one being reduced
+            f32x4 q0[LA + 1], q5[LA + 1], fq[LA + 1];
+            auto issue = [&](const int st) {
+                const int k = st >> 1;
+                const int qrel = st == 0 ? -5 : (st == 1 ? 0 : ((st & 1) ? -5 * k - 5 : 5 * k));     // first quad, relative to the own one
+                const float* base = rb + k * VLEN + 4 * qrel;
+                const float* fbase = fr + k * FLEN + qrel;
+                q0[st % (LA + 1)] = *reinterpret_cast<const f32x4*>(base);
+                q5[st % (LA + 1)] = *reinterpret_cast<const f32x4*>(base + 20);
+                fq[st % (LA + 1)] = f32x4{fbase[1], fbase[2], fbase[3], fbase[4]};
+            };
+            float core = -INFINITY;                                       // sources every one of the four targets takes
+            // right-type window (sources base .. base+23): target q takes read offsets q .. q+19
+            auto reduce_right = [&](const int st) {
+                const f32x4 a0 = q0[st % (LA + 1)], a5 = q5[st % (LA + 1)], f = fq[st % (LA + 1)];
+                core = mx3(mx3(core, a0.w, f.x), f.y, fmaxf(f.z, f.w));
+                const float lo2 = fmaxf(a0.y, a0.z), hi2 = fmaxf(a5.x, a5.y);
+                m.x = mx3(m.x, a0.x, lo2);
+                m.y = mx3(m.y, lo2, a5.x);
+                m.z = mx3(m.z, a0.z, hi2);
+                m.w = mx3(m.w, hi2, a5.z);
+                // the element no target takes stays live up to here: a register that is dead on arrival is handed to the next
+                // stage's address arithmetic, which then has to wait for this read to land (a queue drain per stage)
+                asm volatile("" ::"v"(a5.w));
+            };
+            // left-type window (sources c-20 .. c+3, c the target-0 end of the window): target q takes read offsets q+1 .. q+20
+            auto reduce_left = [&](const int st) {
+                const f32x4 a0 = q0[st % (LA + 1)], a5 = q5[st % (LA + 1)], f = fq[st % (LA + 1)];
+                core = mx3(mx3(core, a5.x, f.x), f.y, fmaxf(f.z, f.w));
+                const float lo2 = fmaxf(a0.z, a0.w), hi2 = fmaxf(a5.y, a5.z);
+                m.x = mx3(m.x, a0.y, lo2);
+                m.y = mx3(m.y, lo2, a5.y);
+                m.z = mx3(m.z, a0.w, hi2);
+                m.w = mx3(m.w, hi2, a5.w);
+                asm volatile("" ::"v"(a0.x));
+            };
 #pragma unroll
-                for (int u = 0; u < 11; ++u) {
-                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(rb - 20 + 4 * u);
-                    x[4 * u] = v4.x; x[4 * u + 1] = v4.y; x[4 * u + 2] = v4.z; x[4 * u + 3] = v4.w;
+            for (int st = 0; st < LA; ++st) issue(st);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int st = 0; st < 2 * KB; ++st) {
+                if (st + LA < 2 * KB) issue(st + LA);
+                asm volatile("" ::: "memory");
+                if (st & 1) {
+                    if (st == 1) reduce_right(st); else reduce_left(st);
+                } else {
+                    if (st == 0) reduce_left(st); else reduce_right(st);
                 }
-                auto X = [&](int off) { return x[off + 20]; };
-                float core = -INFINITY;
-#pragma unroll
-                for (int o = -16; o + 1 <= 19; o += 2) core = mx3(core, X(o), X(o + 1));
-                m.x = mx3(fmaxf(core, X(-19)), X(-18), X(-17));
-                m.y = mx3(fmaxf(core, X(-18)), X(-17), X(20));
-                m.z = mx3(fmaxf(core, X(-17)), X(20), X(21));
-                m.w = mx3(fmaxf(core, X(20)), X(21), X(22));
             }
-#pragma unroll
-            for (int k = 1; k < KB; ++k) {
-                const float* rk = rb + k * VLEN;
-                // right side: target q takes k*BW + q .. k*BW + q + 19; read k*BW .. k*BW + 23, shared core +3 .. +19
-                {
-                    float x[24];
-#pragma unroll
-                    for (int u = 0; u < 6; ++u) {
-                        const f32x4 v4 = *reinterpret_cast<const f32x4*>(rk + k * BW + 4 * u);
-                        x[4 * u] = v4.x; x[4 * u + 1] = v4.y; x[4 * u + 2] = v4.z; x[4 * u + 3] = v4.w;
-                    }
-                    float core = x[3];
-#pragma unroll
-                    for (int o = 4; o + 1 <= 19; o += 2) core = mx3(core, x[o], x[o + 1]);
-                    m.x = fmaxf(m.x, mx3(fmaxf(core, x[0]), x[1], x[2]));
-                    m.y = fmaxf(m.y, mx3(fmaxf(core, x[1]), x[2], x[20]));
-                    m.z = fmaxf(m.z, mx3(fmaxf(core, x[2]), x[20], x[21]));
-                    m.w = fmaxf(m.w, mx3(fmaxf(core, x[20]), x[21], x[22]));
-                }
-                // left side: target q takes q - k*BW - 19 .. q - k*BW; read -k*BW - 20 .. -k*BW + 3, shared core -16 .. 0 (rel. -k*BW)
-                {
-                    float x[24];
-#pragma unroll
-                    for (int u = 0; u < 6; ++u) {
-                        const f32x4 v4 = *reinterpret_cast<const f32x4*>(rk - k * BW - 20 + 4 * u);
-                        x[4 * u] = v4.x; x[4 * u + 1] = v4.y; x[4 * u + 2] = v4.z; x[4 * u + 3] = v4.w;
-                    }
-                    auto X = [&](int off) { return x[off + 20]; };            // off relative to -k*BW
-                    float core = X(-16);
-#pragma unroll
-                    for (int o = -15; o + 1 <= 0; o += 2) core = mx3(core, X(o), X(o + 1));
-                    m.x = fmaxf(m.x, mx3(fmaxf(core, X(-19)), X(-18), X(-17)));
-                    m.y = fmaxf(m.y, mx3(fmaxf(core, X(-18)), X(-17), X(1)));
-                    m.z = fmaxf(m.z, mx3(fmaxf(core, X(-17)), X(1), X(2)));
-                    m.w = fmaxf(m.w, mx3(fmaxf(core, X(1)), X(2), X(3)));
-                }
-            }
+            m = f32x4{fmaxf(m.x, core), fmaxf(m.y, core), fmaxf(m.z, core), fmaxf(m.w, core)};
             // the far sources and the unvoiced source: one maximum
             const f32x4 w = *reinterpret_cast<const f32x4*>(wm + b * 4);
             const float M = fmaxf(fmaxf(w.x, w.y), fmaxf(w.z, w.w));
@@ -568,18 +592,24 @@ __global__ void __launch_bounds__(256) step4_forward_kernel(FwdArgs a) {
         } else {
             // the unvoiced target: every source through its own (arbitrary) row
             float mm = -INFINITY;
+            const float du = dun[b];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                const int i = lane + 64 * q;
-                const float d = i < n ? dl[b * DLEN + i] : (i == n ? dun[b] : -INFINITY);
+                const int i = lane + 64 * q;                               // < DLEN; entries n .. DLEN-1 of dl hold -inf
+                const float d = i == n ? du : dl[b * DLEN + i];
                 mm = fmaxf(mm, d + rown[q]);
             }
             m.x = wave_max_all(mm);
         }
         dn = mask4(m + e_slot);
+        const unsigned long long s3 = prof ? stamp() : 0ull;
         const int tn = t + PF < Tb ? t + PF : Tb - 1;
         store4(t, dn);
         e_slot = load4(tn);
+        if (prof) {
+            const unsigned long long s4 = stamp();
+            ph0 += s1 - s0; ph1 += s2 - s1; ph2 += s3 - s2; ph3 += s4 - s3;
+        }
     };
     int t = 1;
     for (; t + PF - 1 < Tb; t += PF) {
@@ -589,6 +619,11 @@ __global__ void __launch_bounds__(256) step4_forward_kernel(FwdArgs a) {
 #pragma unroll
     for (int k = 0; k < PF - 1; ++k)
         if (t + k < Tb) frame(t + k, er[k], (k + 1) & 1);
+    if (prof && lane == 0 && Tb > 1) {
+        float* o = a.fmax + (size_t)song * 64 + 4 * wv;
+        const float nf = (float)(Tb - 1);
+        o[0] = (float)ph0 / nf; o[1] = (float)ph1 / nf; o[2] = (float)ph2 / nf; o[3] = (float)ph3 / nf;
+    }
 
     // terminal state: lowest-index argmax; a voiced lane holds four adjacent states
     __syncthreads();
@@ -1906,7 +1941,7 @@ hipError_t launch_step(const FwdArgs& a, bool f16, hipStream_t st) {
     const size_t lds = sizeof(float) * (2 * KB * VLEN + 2 * (NWV * 64 + 64) + 2 * 16) + sizeof(VI) * 16;
     if (a.step_form != 1) {     // four targets per lane (step_form 1 selects the one-target form for A/B)
         constexpr int VL4 = 768 + 2 * (KB * BW + BW);
-        const size_t lds4 = sizeof(float) * (2 * KB * VL4 + 2 * (768 + 64) + 2 * 4 + 4) + sizeof(VI) * 16;
+        const size_t lds4 = sizeof(float) * (2 * KB * VL4 + 2 * KB * (VL4 / 4) + 2 * (768 + 64) + 2 * 4 + 4) + sizeof(VI) * 16;
         if (f16)
             hipLaunchKernelGGL((step4_forward_kernel<BW, KB, PF, __half>), dim3((int)a.B), dim3(256), lds4, st, a);
         else
