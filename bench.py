@@ -87,7 +87,7 @@ def forward_kernel_name(dec, algo, B, S):
         pair = info["pair_ok"] and B > 256 and nwt <= 8 and info["group_window"] <= 32
         return "banded_floor_pair_forward_kernel" if pair else "banded_floor_forward_kernel"
     if algo == "auto" and info["step_ok"]:
-        return "step4_forward_kernel"
+        return "step4s_forward_kernel"
     return "dense_forward_kernel"
 
 
@@ -112,6 +112,42 @@ def time_serial(dec, E, algo, steps, warmup=1):
     fwd = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     bt = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
     return {"wall_ms_per_step": wall / steps * 1e3, "forward_ms": fwd, "backtrace_ms": bt}, st, ll
+
+
+def time_overlapped(dec, E, algo, steps, warmup=1):
+    """The headline's schedule on any batch: the back-trace of step i on a second stream under the forward pass of step i+1
+    (two workspace slots, two path buffers); wall time per step over `steps` complete steps."""
+    B, T, _ = E.shape
+    dev = E.device
+    st = [torch.empty((B, T), dtype=torch.int32, device=dev) for _ in range(2)]
+    ll = [torch.empty((B,), dtype=torch.float32, device=dev) for _ in range(2)]
+    for k in range(2):
+        dec._workspace(B, T, k)
+    s_fwd, s_bt = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    bt_done = [None, None]
+
+    def run(n):
+        for i in range(n):
+            k = i & 1
+            with torch.cuda.stream(s_fwd):
+                if bt_done[k] is not None:
+                    s_fwd.wait_event(bt_done[k])
+                dec.decode_into(E, st[k], ll[k], algo=algo, phase="forward", slot=k)
+                fwd_done = torch.cuda.Event()
+                fwd_done.record()
+            with torch.cuda.stream(s_bt):
+                s_bt.wait_event(fwd_done)
+                dec.decode_into(E, st[k], ll[k], algo=algo, phase="backtrace", slot=k)
+                bt_done[k] = torch.cuda.Event()
+                bt_done[k].record()
+        torch.cuda.synchronize()
+
+    run(warmup)
+    t0 = time.perf_counter()
+    run(steps)
+    wall = (time.perf_counter() - t0) / steps * 1e3
+    dec._ws_slots.clear()
+    return wall, st[(steps - 1) & 1], ll[(steps - 1) & 1]
 
 
 def cpu_baseline(logA_T, log_pi, E, gpu_states, gpu_loglik, seconds):
@@ -220,12 +256,18 @@ def extra_blocks(dev, args):
                   "forward_hbm_frac": fb / (r["forward_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                   "whole_path_hbm_frac": B * T * 2172 / ((r["forward_ms"] + r["backtrace_ms"]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                   "bit_exact_vs_oracle_sample": oracle_spot_check(logA_T, log_pi, E, st, ll, [0, 17, 31])})
+        if B <= 1024:     # (two workspace slots of 2048 songs do not fit beside the emissions)
+            wall, st2, ll2 = time_overlapped(dec, E, "banded", steps=4)
+            r.update({"overlapped_ms_per_step": wall, "Mframes_per_s_overlapped": B * T / wall / 1e3,
+                      "overlapped_equals_serial": bool(torch.equal(st2, st) and torch.equal(ll2, ll))})
+            del st2, ll2
         sweep[f"B{B}"] = r
         del E, st, ll
         dec._ws = None
         torch.cuda.empty_cache()
     out["sweep"] = {"workload": f"T={T}, S=361, fp32 log-emissions (peaks), tonet transition; songs repeat with period 32; "
-                                "forward + back-trace back to back on one stream, 3 steps", **sweep}
+                                "forward + back-trace back to back on one stream, 3 steps (Mframes_per_s); "
+                                "*_overlapped: the headline's two-stream schedule, 4 steps", **sweep}
     del dec
     # ---- configs[4]: S=722 (721 bins + unvoiced), fp16 emissions, 256 songs
     c4 = {}

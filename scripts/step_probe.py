@@ -18,7 +18,7 @@ for B in (64, 128, 256, 512, 1024):
     E = base.repeat(B // 32, 1, 1).contiguous()
     st = torch.empty((B, T), dtype=torch.int32, device=dev)
     ll = torch.empty((B,), dtype=torch.float32, device=dev)
-    for form in (0, 1):
+    for form in (0, 3, 1):
         dec.set_option("step_form", form)
         dec.decode_into(E, st, ll, phase="forward")
         torch.cuda.synchronize()
@@ -47,6 +47,6 @@ ws = dec._ws
 a256 = lambda x: (x + 255) // 256 * 256
 off = dec.workspace_bytes(B, T) - a256(B * 32 * 4) - a256(B * 4) - a256(B * 64 * 4)
 sc = ws[off:off + B * 64 * 4].view(torch.float32).view(B, 64).cpu().numpy()
-for w in range(4):
+for w in range(7):
     ph = sc[:, 4 * w:4 * w + 4]
     print(f"wave {w}: publish {ph[:,0].mean():.0f}  barrier {ph[:,1].mean():.0f}  consume {ph[:,2].mean():.0f}  store+prefetch {ph[:,3].mean():.0f}  (cycles, mean over songs)")

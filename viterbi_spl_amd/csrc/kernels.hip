@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "kernels.hpp"
 
@@ -651,6 +652,291 @@ __global__ void __launch_bounds__(256) step4_forward_kernel(FwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Step-structured forward kernel, four targets per lane, the bands split over two waves per lane group (what runs for
+// the Durrieu matrix).
+//
+// Same arithmetic as step4_forward_kernel.  With one workgroup per CU (B = 256 on 256 CUs) that kernel has one wave per
+// SIMD, and a lone wave issues one vector instruction per ~4 cycles: its ~50 publish and ~270 consume instructions ARE the
+// frame time.  Here every group of 192 lanes x 4 states exists twice: waves 0-2 (half A) publish V_k and F_k for the bands
+// k = 0..4 and reduce the read stages 0..8, waves 3-5 (half B) take k = 5..8, delta itself, the far-band maximum and the
+// stages 9..17; the halves swap their partial maxima through LDS (one float4 each way) behind a second barrier and both form
+// delta_t.  Two waves per SIMD issue alternately (2 cycles per instruction), each half moves half the bytes through the LDS
+// store path, and with a barrier on either side of the reads V needs no second buffer: 60 KB of LDS instead of 112.
+// ---------------------------------------------------------------------------------------
+template <int BW, int KB, int PF, typename ET>
+__global__ void __launch_bounds__(448) step4s_forward_kernel(FwdArgs a) {
+    static_assert(BW == 20 && KB == 9 && PF % 2 == 0, "written for nine 20-bin bands");
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int NQL = 192;                      // lanes per half: 192 x 4 states
+    constexpr int NPV = 4 * NQL;                  // padded voiced states
+    constexpr int PAD = KB * BW + BW;             // -inf margin on both sides of every V_k (multiple of 4)
+    constexpr int VLEN = NPV + 2 * PAD;
+    constexpr int FLEN = VLEN / 4;
+    constexpr int DLEN = NPV + 64;
+    constexpr int KA = 5;                         // half A: bands 0 .. KA-1; half B: KA .. KB-1 and the far band KB
+    constexpr int NST = 2 * KB, STA = 9;          // read stages; half A takes 0 .. STA-1
+    float* V = reinterpret_cast<float*>(smem);    // [KB][VLEN]
+    float* F = V + KB * VLEN;                     // [KB][FLEN]  F_k[u] = max of the quad V_k[4u .. 4u+3]
+    float* dl = F + KB * FLEN;                    // [DLEN]      delta of the voiced states (for the unvoiced target's row)
+    f32x4* X = reinterpret_cast<f32x4*>(dl + DLEN);   // [2][NQL]    partial maxima of the two halves
+    float* wm = reinterpret_cast<float*>(X + 2 * NQL);   // [4]  wave maxima of V_KB (half B), slot 3 = the unvoiced source's candidate
+    float* dun = wm + 4;                          // [1 (+3)]    delta of the unvoiced state
+    VI* tot = reinterpret_cast<VI*>(dun + 4);
+    const int S = a.S, SP = a.SP, T = a.T, SD = a.SD;
+    const int n = S - 1;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wv < 3 ? 0 : (wv < 6 ? 1 : 2);                        // 2: the unvoiced state's wave
+    const int ql = tid - NQL * (half == 1 ? 1 : 0);                       // lane within the half (halves 0, 1)
+    const int song = blockIdx.x;
+    const int Tb = song_length(a.lengths, song, T);
+    const ET* __restrict__ E = reinterpret_cast<const ET*>(a.logE) + (size_t)song * T * S;
+    float* __restrict__ hist = a.hist + (size_t)song * T * SD;
+    const float* __restrict__ lpi = reinterpret_cast<const float*>(a.image + a.off_logpi);
+
+    for (int k = tid; k < KB * VLEN + KB * FLEN + DLEN + 8 * NQL + 8; k += 448) V[k] = -INFINITY;
+    __syncthreads();
+
+    const bool voiced_wave = half < 2;
+    const int j0 = 4 * ql;                                                // voiced lanes: first of the four own states
+    bool val[4];
+    int col[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        val[q] = voiced_wave && j0 + q < n;
+        col[q] = voiced_wave ? (j0 + q < n ? j0 + q : n - 1) : n;          // emission column loaded (unvoiced wave: column n)
+    }
+    const bool all4 = voiced_wave && j0 + 3 < n;
+    const int k0 = half == 1 ? KA : 0;                                    // first band of this half
+    f32x4 c[KA];                                                          // half A: C_0 .. C_4; half B: C_5 .. C_8 and the far band C_9
+    {
+        const float* __restrict__ sc = reinterpret_cast<const float*>(a.image + a.off_stepC);
+#pragma unroll
+        for (int i = 0; i < KA; ++i) {
+            const int k = k0 + i;
+            c[i].x = val[0] ? sc[(size_t)k * SP + j0 + 0] : -INFINITY;
+            c[i].y = val[1] ? sc[(size_t)k * SP + j0 + 1] : -INFINITY;
+            c[i].z = val[2] ? sc[(size_t)k * SP + j0 + 2] : -INFINITY;
+            c[i].w = val[3] ? sc[(size_t)k * SP + j0 + 3] : -INFINITY;
+        }
+    }
+    constexpr int NQ = 13;                                                // sources per lane of the unvoiced target's wave
+    float rown[NQ];
+    {
+        const float* __restrict__ ar = reinterpret_cast<const float*>(a.image + a.off_Arow) + (size_t)n * SP;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) rown[q] = (!voiced_wave && lane + 64 * q < SP) ? ar[lane + 64 * q] : -INFINITY;
+    }
+    const float cn = a.step_cn;
+
+    auto load4 = [&](const int row) -> f32x4 {
+        const ET* __restrict__ r = E + (size_t)row * S;
+        return f32x4{load_e<ET>(r + col[0]), load_e<ET>(r + col[1]), load_e<ET>(r + col[2]), load_e<ET>(r + col[3])};
+    };
+    auto store4 = [&](const int row, const f32x4 d) {                     // half A and the unvoiced wave only
+        float* __restrict__ h = hist + (size_t)row * SD;
+        if (half == 0) {
+            if (all4) {
+                *reinterpret_cast<f32x4*>(h + j0) = d;
+            } else {
+                if (val[0]) h[j0] = d.x;
+                if (val[1]) h[j0 + 1] = d.y;
+                if (val[2]) h[j0 + 2] = d.z;
+            }
+        } else if (half == 2 && lane == 0) {
+            h[n] = d.x;
+        }
+    };
+    auto mask4 = [&](const f32x4 d) -> f32x4 {
+        if (!voiced_wave) return d;
+        return f32x4{val[0] ? d.x : -INFINITY, val[1] ? d.y : -INFINITY, val[2] ? d.z : -INFINITY, val[3] ? d.w : -INFINITY};
+    };
+    auto mx3 = [](float acc, float x, float y) { return fmaxf(fmaxf(acc, x), y); };
+
+    f32x4 dn;                                                             // delta of the own states (unvoiced wave: .x = state n, every lane)
+    {
+        const f32x4 e0 = load4(0);
+        dn = mask4(f32x4{lpi[col[0]], lpi[col[1]], lpi[col[2]], lpi[col[3]]} + e0);
+        store4(0, dn);
+    }
+    f32x4 er[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) er[k] = load4(1 + k < Tb ? 1 + k : Tb - 1);
+
+#ifdef VIT_TIMING_HOOKS
+    const bool prof = (a.debug & 256) != 0;      // phase stamps: publish | barrier | reads | exchange + store -> scratch[song][4*wave ..]
+#else
+    constexpr bool prof = false;
+#endif
+    unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0;
+    auto stamp = [&]() -> unsigned long long {
+        unsigned long long v;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");
+        return v;
+    };
+
+    const float* rb = V + PAD + j0;                                       // own quad in V_0 (16-byte aligned)
+    const float* fr = F + PAD / 4 + ql;                                   // own quad's slot in F_0
+
+    // reads of one stage (see step4_forward_kernel): Q0, Q5 in full, the four inner quads as their maxima
+    struct Stage { f32x4 q0, q5, f; };
+    auto issue = [&](const int st) -> Stage {
+        const int k = st >> 1;
+        const int qrel = st == 0 ? -5 : (st == 1 ? 0 : ((st & 1) ? -5 * k - 5 : 5 * k));
+        const float* base = rb + k * VLEN + 4 * qrel;
+        const float* fbase = fr + k * FLEN + qrel;
+        Stage r;
+        r.q0 = *reinterpret_cast<const f32x4*>(base);
+        r.q5 = *reinterpret_cast<const f32x4*>(base + 20);
+        r.f = f32x4{fbase[1], fbase[2], fbase[3], fbase[4]};
+        return r;
+    };
+
+    auto frame = [&](const int t, f32x4& e_slot) {
+        const unsigned long long s0 = prof ? stamp() : 0ull;
+        // ---- publish delta_{t-1}
+        if (voiced_wave) {
+            float* vb = V + PAD + j0 + k0 * VLEN;
+            float* fb = F + PAD / 4 + ql + k0 * FLEN;
+#pragma unroll
+            for (int i = 0; i < KA; ++i) {
+                if (i < KA - 1 || half == 0) {                            // half B's fifth constant is the far band
+                    const f32x4 vq = dn + c[i];
+                    *reinterpret_cast<f32x4*>(vb + i * VLEN) = vq;
+                    fb[i * FLEN] = fmaxf(fmaxf(fmaxf(vq.x, vq.y), vq.z), vq.w);
+                }
+            }
+            if (half == 1) {
+                *reinterpret_cast<f32x4*>(dl + j0) = dn;
+                const f32x4 vf = dn + c[KA - 1];
+                const float inc = wave_scan_max(fmaxf(fmaxf(vf.x, vf.y), fmaxf(vf.z, vf.w)));
+                if (lane == 63) wm[wv - 3] = inc;
+            }
+        } else if (lane == 0) {
+            dun[0] = dn.x;
+            wm[3] = dn.x + cn;
+        }
+        const unsigned long long s1 = prof ? stamp() : 0ull;
+        __syncthreads();
+        const unsigned long long s2 = prof ? stamp() : 0ull;
+        // ---- reads
+        f32x4 m = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (voiced_wave) {
+            float core = -INFINITY;                                       // sources every one of the four targets takes
+            auto reduce_right = [&](const Stage& r) {                     // target q takes read offsets q .. q+19
+                const f32x4 a0 = r.q0, a5 = r.q5, f = r.f;
+                core = mx3(mx3(core, a0.w, f.x), f.y, fmaxf(f.z, f.w));
+                const float lo2 = fmaxf(a0.y, a0.z), hi2 = fmaxf(a5.x, a5.y);
+                m.x = mx3(m.x, a0.x, lo2);
+                m.y = mx3(m.y, lo2, a5.x);
+                m.z = mx3(m.z, a0.z, hi2);
+                m.w = mx3(m.w, hi2, a5.z);
+                asm volatile("" ::"v"(a5.w));                             // (keeps a dead-on-arrival register out of the address arithmetic)
+            };
+            auto reduce_left = [&](const Stage& r) {                      // target q takes read offsets q+1 .. q+20
+                const f32x4 a0 = r.q0, a5 = r.q5, f = r.f;
+                core = mx3(mx3(core, a5.x, f.x), f.y, fmaxf(f.z, f.w));
+                const float lo2 = fmaxf(a0.z, a0.w), hi2 = fmaxf(a5.y, a5.z);
+                m.x = mx3(m.x, a0.y, lo2);
+                m.y = mx3(m.y, lo2, a5.y);
+                m.z = mx3(m.z, a0.w, hi2);
+                m.w = mx3(m.w, hi2, a5.w);
+                asm volatile("" ::"v"(a0.x));
+            };
+            constexpr int LA = 2;                                         // stages in flight ahead of the one being reduced
+            auto run = [&](auto first, auto last) {
+                constexpr int ST0 = decltype(first)::value, ST1 = decltype(last)::value;
+                Stage buf[LA + 1];
+#pragma unroll
+                for (int st = ST0; st < ST0 + LA; ++st) buf[(st - ST0) % (LA + 1)] = issue(st);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int st = ST0; st < ST1; ++st) {
+                    if (st + LA < ST1) buf[(st + LA - ST0) % (LA + 1)] = issue(st + LA);
+                    asm volatile("" ::: "memory");
+                    const bool left = st == 0 || (st >= 2 && (st & 1));
+                    if (left) reduce_left(buf[(st - ST0) % (LA + 1)]); else reduce_right(buf[(st - ST0) % (LA + 1)]);
+                }
+            };
+            if (half == 0) {
+                run(std::integral_constant<int, 0>{}, std::integral_constant<int, STA>{});
+            } else {
+                run(std::integral_constant<int, STA>{}, std::integral_constant<int, NST>{});
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wm);        // the far sources and the unvoiced source: one maximum
+                core = fmaxf(core, fmaxf(fmaxf(w.x, w.y), fmaxf(w.z, w.w)));
+            }
+            m = f32x4{fmaxf(m.x, core), fmaxf(m.y, core), fmaxf(m.z, core), fmaxf(m.w, core)};
+            X[half * NQL + ql] = m;
+        } else {
+            // the unvoiced target: every source through its own (arbitrary) row
+            float mm = -INFINITY;
+            const float du = dun[0];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int i = lane + 64 * q;                               // < DLEN; entries n .. DLEN-1 of dl hold -inf
+                const float d = i == n ? du : dl[i];
+                mm = fmaxf(mm, d + rown[q]);
+            }
+            m.x = wave_max_all(mm);
+        }
+        const unsigned long long s3 = prof ? stamp() : 0ull;
+        __syncthreads();
+        // ---- both halves form delta_t
+        if (voiced_wave) {
+            const f32x4 o = X[(1 - half) * NQL + ql];
+            m = f32x4{fmaxf(m.x, o.x), fmaxf(m.y, o.y), fmaxf(m.z, o.z), fmaxf(m.w, o.w)};
+        }
+        dn = mask4(m + e_slot);
+        const int tn = t + PF < Tb ? t + PF : Tb - 1;
+        store4(t, dn);
+        e_slot = load4(tn);
+        if (prof) {
+            const unsigned long long s4 = stamp();
+            ph0 += s1 - s0; ph1 += s2 - s1; ph2 += s3 - s2; ph3 += s4 - s3;
+        }
+    };
+    int t = 1;
+    for (; t + PF - 1 < Tb; t += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) frame(t + k, er[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < PF - 1; ++k)
+        if (t + k < Tb) frame(t + k, er[k]);
+    if (prof && lane == 0 && Tb > 1) {
+        float* o = a.fmax + (size_t)song * 64 + 4 * wv;
+        const float nf = (float)(Tb - 1);
+        o[0] = (float)ph0 / nf; o[1] = (float)ph1 / nf; o[2] = (float)ph2 / nf; o[3] = (float)ph3 / nf;
+    }
+
+    // terminal state: lowest-index argmax over half A's lanes (four adjacent states each) and the unvoiced state
+    __syncthreads();
+    {
+        VI x = vi_identity();
+        if (half == 0) {
+            if (val[0]) x = VI{dn.x, j0};
+            if (val[1]) x = op_fwd(x, VI{dn.y, j0 + 1});
+            if (val[2]) x = op_fwd(x, VI{dn.z, j0 + 2});
+            if (val[3]) x = op_fwd(x, VI{dn.w, j0 + 3});
+        } else if (half == 2 && lane == 0) {
+            x = VI{dn.x, n};
+        }
+        x = wave_scan<false>(x);
+        if (lane == 63) tot[wv] = x;
+        __syncthreads();
+        if (tid == 0) {
+            VI acc = vi_identity();
+            for (int bq = 0; bq < 7; ++bq) acc = op_fwd(acc, tot[bq]);
+            if (acc.i == kBig) acc.i = 0;
+            a.last_state[song] = acc.i;
+            if (a.loglik) a.loglik[song] = acc.v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Banded forward kernel: one song per workgroup, value-only.
 //
 // For a banded target j (window [lo_j, lo_j+W), row constant c_j, extra columns X):
@@ -1047,18 +1333,26 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
         // ---- everything this frame reads from LDS: the window, the extra columns, the wave maxima
         const f32x4* __restrict__ win = reinterpret_cast<const f32x4*>(rp + RB * BUF);
         float xd[NXL > 0 ? NXL : 1];
-#pragma unroll
-        for (int k = 0; k < NXL; ++k) xd[k] = dls[4 + sh + RB * BUF + xcol[k]];
         // the NWT wave maxima: whole float4s, plus one float2 when NWT % 4 is 2 or 3 (slots >= NWT hold -inf)
         f32x4 wq[NWT / 4 > 0 ? NWT / 4 : 1];
         f32x2 wr = f32x2{-INFINITY, -INFINITY};
         float wl = -INFINITY;
+        // The small reads go out first and the first chunk of the window right behind them, and only then is M reduced: left to
+        // itself the compiler reduces M before it issues the window reads -- a full LDS round trip with nothing else in flight.
+        // (M reduced last instead lengthens the dependent tail after the last window read lands: measured slower.)
+        auto small_reads = [&]() {
 #pragma unroll
-        for (int q = 0; q < NWT / 4; ++q) wq[q] = reinterpret_cast<const f32x4*>(wm + RB * NWM)[q];
-        if (NWT % 4 >= 2) wr = *reinterpret_cast<const f32x2*>(wm + RB * NWM + (NWT / 4) * 4);
-        if (NWT % 4 == 1 || NWT % 4 == 3) wl = wm[RB * NWM + NWT - 1];
+            for (int k = 0; k < NXL; ++k) xd[k] = dls[4 + sh + RB * BUF + xcol[k]];
+#pragma unroll
+            for (int q = 0; q < NWT / 4; ++q) wq[q] = reinterpret_cast<const f32x4*>(wm + RB * NWM)[q];
+            if (NWT % 4 >= 2) wr = *reinterpret_cast<const f32x2*>(wm + RB * NWM + (NWT / 4) * 4);
+            if (NWT % 4 == 1 || NWT % 4 == 3) wl = wm[RB * NWM + NWT - 1];
+        };
         // the window in chunks of 32 sources (8 reads): wide windows (W = 96, 128) must not hold all their data at once
         float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+        float M = -INFINITY;
+        small_reads();
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int w0 = 0; w0 < W; w0 += 32) {
         // W > 64: one chunk of reads in flight at a time (W register-resident weights leave no room for more; with
@@ -1068,6 +1362,16 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
 #pragma unroll
         for (int q = 0; q < 8; ++q)
             if (w0 + 4 * q < W) dw[q] = win[w0 / 4 + q];
+        if (w0 == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            // M = max of delta_{t-1} over the non-extra sources
+            M = wl;
+            if (NWT % 4 >= 2) M = fmaxf(fmaxf(M, wr.x), wr.y);
+#pragma unroll
+            for (int q = 0; q < NWT / 4; ++q) M = fmaxf(fmaxf(fmaxf(M, wq[q].x), wq[q].y), fmaxf(wq[q].z, wq[q].w));
+            m0 = M + cj;
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int w = w0; w + 7 < W && w < w0 + 32; w += 8) {
             const f32x4 da = dw[(w - w0) / 4], db = dw[(w - w0) / 4 + 1];
@@ -1089,12 +1393,6 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
             m3 = fmaxf(fmaxf(m3, c3_.x), c3_.y);
         }
         }
-        // M = max of delta_{t-1} over the non-extra sources
-        float M = wl;
-        if (NWT % 4 >= 2) M = fmaxf(fmaxf(M, wr.x), wr.y);
-#pragma unroll
-        for (int q = 0; q < NWT / 4; ++q) M = fmaxf(fmaxf(fmaxf(M, wq[q].x), wq[q].y), fmaxf(wq[q].z, wq[q].w));
-        m0 = fmaxf(m0, M + cj);
 #pragma unroll
         for (int k = 0; k < NXL; ++k) m1 = fmaxf(m1, xd[k] + xa[k]);
         const float dn = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)) + e_slot;
@@ -1939,7 +2237,16 @@ hipError_t launch_step(const FwdArgs& a, bool f16, hipStream_t st) {
     if (!step_kernel_instantiated(a.S, a.step_bw, a.step_kb)) return hipErrorInvalidConfiguration;
     constexpr int VLEN = NWV * 64 + 2 * (KB * BW + BW);
     const size_t lds = sizeof(float) * (2 * KB * VLEN + 2 * (NWV * 64 + 64) + 2 * 16) + sizeof(VI) * 16;
-    if (a.step_form != 1) {     // four targets per lane (step_form 1 selects the one-target form for A/B)
+    if (a.step_form == 0) {     // four targets per lane, bands split over two waves (step_form 2: one wave, 1: one target per lane)
+        constexpr int VL4 = 768 + 2 * (KB * BW + BW);
+        const size_t ldss = sizeof(float) * (KB * VL4 + KB * (VL4 / 4) + (768 + 64) + 8 * 192 + 8) + sizeof(VI) * 16;
+        if (f16)
+            hipLaunchKernelGGL((step4s_forward_kernel<BW, KB, PF, __half>), dim3((int)a.B), dim3(448), ldss, st, a);
+        else
+            hipLaunchKernelGGL((step4s_forward_kernel<BW, KB, PF, float>), dim3((int)a.B), dim3(448), ldss, st, a);
+        return hipGetLastError();
+    }
+    if (a.step_form != 1) {
         constexpr int VL4 = 768 + 2 * (KB * BW + BW);
         const size_t lds4 = sizeof(float) * (2 * KB * VL4 + 2 * KB * (VL4 / 4) + 2 * (768 + 64) + 2 * 4 + 4) + sizeof(VI) * 16;
         if (f16)
