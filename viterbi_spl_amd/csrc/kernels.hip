@@ -658,8 +658,8 @@ __global__ void __launch_bounds__(256) step4_forward_kernel(FwdArgs a) {
 // Same arithmetic as step4_forward_kernel.  With one workgroup per CU (B = 256 on 256 CUs) that kernel has one wave per
 // SIMD, and a lone wave issues one vector instruction per ~4 cycles: its ~50 publish and ~270 consume instructions ARE the
 // frame time.  Here every group of 192 lanes x 4 states exists twice: waves 0-2 (half A) publish V_k and F_k for the bands
-// k = 0..4 and reduce the read stages 0..8, waves 3-5 (half B) take k = 5..8, delta itself, the far-band maximum and the
-// stages 9..17; the halves swap their partial maxima through LDS (one float4 each way) behind a second barrier and both form
+// k = 0..4 and delta itself and reduce the read stages 0..9, waves 3-5 (half B) take k = 5..8, the far-band maximum and the
+// stages 10..17; the halves swap their partial maxima through LDS (one float4 each way) behind a second barrier and both form
 // delta_t.  Two waves per SIMD issue alternately (2 cycles per instruction), each half moves half the bytes through the LDS
 // store path, and with a barrier on either side of the reads V needs no second buffer: 60 KB of LDS instead of 112.
 // ---------------------------------------------------------------------------------------
@@ -674,7 +674,7 @@ __global__ void __launch_bounds__(448) step4s_forward_kernel(FwdArgs a) {
     constexpr int FLEN = VLEN / 4;
     constexpr int DLEN = NPV + 64;
     constexpr int KA = 5;                         // half A: bands 0 .. KA-1; half B: KA .. KB-1 and the far band KB
-    constexpr int NST = 2 * KB, STA = 9;          // read stages; half A takes 0 .. STA-1
+    constexpr int NST = 2 * KB, STA = 10;         // read stages; half A takes 0 .. STA-1 (half B also reduces the far band and scans)
     float* V = reinterpret_cast<float*>(smem);    // [KB][VLEN]
     float* F = V + KB * VLEN;                     // [KB][FLEN]  F_k[u] = max of the quad V_k[4u .. 4u+3]
     float* dl = F + KB * FLEN;                    // [DLEN]      delta of the voiced states (for the unvoiced target's row)
@@ -808,8 +808,8 @@ __global__ void __launch_bounds__(448) step4s_forward_kernel(FwdArgs a) {
                     fb[i * FLEN] = fmaxf(fmaxf(fmaxf(vq.x, vq.y), vq.z), vq.w);
                 }
             }
+            if (half == 0) *reinterpret_cast<f32x4*>(dl + j0) = dn;
             if (half == 1) {
-                *reinterpret_cast<f32x4*>(dl + j0) = dn;
                 const f32x4 vf = dn + c[KA - 1];
                 const float inc = wave_scan_max(fmaxf(fmaxf(vf.x, vf.y), fmaxf(vf.z, vf.w)));
                 if (lane == 63) wm[wv - 3] = inc;
