@@ -114,6 +114,22 @@ def time_serial(dec, E, algo, steps, warmup=1):
     return {"wall_ms_per_step": wall / steps * 1e3, "forward_ms": fwd, "backtrace_ms": bt}, st, ll
 
 
+VALU_LANE_RATE = 256 * 4 * 16 * 2.4e9   # lane-instructions per second: 256 CUs x 4 SIMDs x 16 lanes per clock at 2.4 GHz
+
+
+def valu_ceiling(dec, S, frames, fwd_ms):
+    """Frames per second if the forward kernel were bound by vector-instruction issue alone: candidates per state (window + floor
+    + extra columns), one lane-instruction each (half a v_pk_add_f32 + half a v_max3_f32), nothing else counted."""
+    info = dec.info
+    if not info.get("banded_ok"):
+        return None
+    cand = info["max_window"] + 1 + info["n_extras"]
+    per_frame = S * cand
+    peak = VALU_LANE_RATE / per_frame
+    return {"candidates_per_state": cand, "lane_instructions_per_frame": per_frame, "peak_Mframes_per_s": peak / 1e6,
+            "achieved_Mframes_per_s": frames / (fwd_ms * 1e-3) / 1e6, "frac": frames / (fwd_ms * 1e-3) / peak}
+
+
 def time_overlapped(dec, E, algo, steps, warmup=1):
     """The headline's schedule on any batch: the back-trace of step i on a second stream under the forward pass of step i+1
     (two workspace slots, two path buffers); wall time per step over `steps` complete steps."""
@@ -254,6 +270,7 @@ def extra_blocks(dev, args):
         r.update({"songs": B, "Mframes_per_s": B * T / (r["forward_ms"] + r["backtrace_ms"]) / 1e3,
                   "forward_kernel": forward_kernel_name(dec, "banded", B, 361),
                   "forward_hbm_frac": fb / (r["forward_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "forward_valu_frac": valu_ceiling(dec, 361, B * T, r["forward_ms"])["frac"],
                   "whole_path_hbm_frac": B * T * 2172 / ((r["forward_ms"] + r["backtrace_ms"]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                   "bit_exact_vs_oracle_sample": oracle_spot_check(logA_T, log_pi, E, st, ll, [0, 17, 31])})
         if B <= 1024:     # (two workspace slots of 2048 songs do not fit beside the emissions)
@@ -445,6 +462,9 @@ def main():
                          "note": "algorithmic bytes per SURVEY 8d (emission row in + uint16 back-pointer row out); the kernels "
                                  "store the float32 delta row instead (lazy back-pointers, DESIGN.md 4.0)"},
             "kernels_ms": {"forward": fwd_ms, "backtrace": bt_ms},
+            # the other ceiling of this recursion: one packed add + one max3 per two candidates and state is the minimum with
+            # exact fp32 sums, and a SIMD issues one wave64 vector instruction per 4 cycles
+            "valu_ceiling": valu_ceiling(dec, S, frames_per_launch, fwd_ms),
             "backtrace": {"algorithmic_bytes_per_launch": frames_per_launch * 6, "traffic": bt_traffic},
             "whole_path_bytes_per_frame": bpf + 6,
             "whole_path_hbm_frac": value * 1e6 * (bpf + 6) / 1e9 / (HBM_PEAK_GBS * world),
