@@ -75,6 +75,8 @@ def emissions_peaks(B: int, T: int, S: int, seed: int = 0, device="cpu", dtype=t
     """Peak-sparse log-emissions mimicking Viterbi.observation_probs_fn
     (tonet/for_paper.py:1733-1778): per frame 0-5 pitch peaks plus the unvoiced
     state (last), every other state exactly log(tiny)."""
+    if S < 8:
+        raise ValueError("emissions_peaks needs at least 8 states (peak positions are drawn from S - 5 centres)")
     if out is None:
         out = torch.empty((B, T, S), dtype=dtype, device=device)
     frames = torch.arange(T, dtype=torch.int64, device=device)
@@ -107,6 +109,8 @@ def emissions_scaled(B: int, T: int, S: int, seed: int = 0, device="cpu", dtype=
     """Peak-sparse log-emissions of a "scaled likelihood" builder (p / prior, dcnet/softmax_viterbi.py:2571-2572 in the
     reference): like :func:`emissions_peaks`, but peak values reach well ABOVE zero (up to +6: a posterior near 1 over a
     prior of a few 1e-3) and the unvoiced state swings between -3 and +3; every other state exactly log(tiny)."""
+    if S < 8:
+        raise ValueError("emissions_scaled needs at least 8 states (peak positions are drawn from S - 5 centres)")
     out = torch.empty((B, T, S), dtype=dtype, device=device)
     frames = torch.arange(T, dtype=torch.int64, device=device)
     for b in range(B):
