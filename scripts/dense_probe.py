@@ -14,11 +14,12 @@ A = synth.dense_random_log_transition(S, seed=3)
 pi = synth.dense_random_log_transition(S, seed=4)[0].copy()
 dec = ViterbiDecoder(A, pi, dev)
 base = synth.emissions_dense(32, T, S, seed=1, device=dev)
-for B in (128, 1024):
+for B in (128, 256, 1024):
     E = base.repeat(B // 32, 1, 1).contiguous()
     st = torch.empty((B, T), dtype=torch.int32, device=dev)
     ll = torch.empty((B,), dtype=torch.float32, device=dev)
-    for ns, kt1 in ((1, 0), (1, 1), (2, 0), (4, 0), (8, 0)):
+    for ns, kt1 in ((0, 0), (1, 0), (2, 0)):
+        dec.set_option("dense_form", 0 if ns == 0 else 1)     # first entry: the matrix-resident form
         dec.set_option("dense_songs", ns)
         dec.set_option("dense_one_thread", kt1)
         dec.decode_into(E, st, ll, algo="dense", phase="forward")
@@ -29,5 +30,5 @@ for B in (128, 1024):
         ev[1].record()
         torch.cuda.synchronize()
         ms = ev[0].elapsed_time(ev[1])
-        wgs = (B + ns - 1) // ns
+        wgs = (B + ns - 1) // ns if ns else B
         print(f"B {B} songs/wg {ns} one_thread {kt1}: {ms:.1f} ms -> {B*T/ms/1e3:.1f} Mframes/s; {ms*1e-3/T*2.4e9:.0f} cycles per frame per workgroup ({wgs} workgroups)", flush=True)

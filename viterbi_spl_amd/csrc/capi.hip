@@ -21,6 +21,7 @@ struct Tuning {
     int backtrace_form = 0;    // 0 auto | 1 generic (lazy) kernel
     int dense_songs = 0;       // songs per workgroup of the dense kernel (0 = by batch size)
     int dense_one_thread = 0;  // 1: one thread per target in the dense kernel even where two fit
+    int dense_form = 0;        // 0: matrix-resident dense kernel where it applies (256 < S <= 368) | 1: always the streaming kernel
     int step_form = 0;         // step-structured kernel: 0 four targets per lane, split | 1 one | 2 never (plain dense kernel) | 3 four, one wave
     int bt_chunks = 0;         // time-parallel back-trace: chunks per song (0 = auto)
     int bt_warm = -1;          //                            warm-up frames (-1 = default)
@@ -191,7 +192,7 @@ size_t vit_workspace_bytes(const vit_plan* plan, int64_t B, int64_t T) {
 static int* tuning_field(Tuning& t, const char* key) {
     struct { const char* k; int Tuning::*f; } const tab[] = {
         {"forward_form", &Tuning::forward_form}, {"backtrace_form", &Tuning::backtrace_form},
-        {"dense_songs", &Tuning::dense_songs}, {"dense_one_thread", &Tuning::dense_one_thread},
+        {"dense_songs", &Tuning::dense_songs}, {"dense_one_thread", &Tuning::dense_one_thread}, {"dense_form", &Tuning::dense_form},
         {"step_form", &Tuning::step_form}, {"bt_chunks", &Tuning::bt_chunks}, {"bt_warm", &Tuning::bt_warm},
         {"win_shift", &Tuning::win_shift}, {"wave_min_batch", &Tuning::wave_min_batch}, {"wave_two", &Tuning::wave_two},
         {"timing", &Tuning::timing},
@@ -267,6 +268,7 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
     a.debug = tn.timing;          // 0 unless built with -DVIT_TIMING_HOOKS (vit_plan_set_option refuses it otherwise)
     a.fwd_form = tn.forward_form >= 1 && tn.forward_form <= 3 ? tn.forward_form : 0;
     a.dense_kt1 = tn.dense_one_thread;
+    a.dense_form = tn.dense_form;
     a.step_form = tn.step_form;
     a.off_logpi = plan->L.off_logpi;
     a.off_A4 = plan->L.off_A4;

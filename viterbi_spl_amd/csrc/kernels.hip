@@ -247,6 +247,134 @@ __global__ void __launch_bounds__(KT == 2 ? 1024 : dense_max_threads(NS)) dense_
 }
 
 // ---------------------------------------------------------------------------------------
+// Dense forward kernel with the matrix RESIDENT on the CU (any matrix, 256 < S <= 368; one song per workgroup).
+//
+// dense_forward_kernel streams 4*S*S bytes of transition entries per frame and workgroup through a 64 B/clk vector L1:
+// ~8100 cycles per frame at S = 361, four times the ~2000 its S*S packed adds and maxima take.  But a CU owns 512 KB of
+// vector registers and 160 KB of LDS and the matrix is 521 KB: two threads per target, each holding its half row (HS = 184
+// sources) as WRG = 132 registers + 13 float4 in LDS (conflict-free [q][thread] layout), keep every entry on the CU for the
+// whole song.  A frame then reads only delta_{t-1}: the half row's 46 float4 as LDS broadcast reads (the even and the odd
+// lanes of a wave read two addresses), 92 packed adds + 92 max3 per thread, one DPP exchange between the two lanes of a
+// target, one barrier.  Same sums, same maxima as the streaming kernel: bit-identical history rows.
+// ---------------------------------------------------------------------------------------
+template <int HS, int WRG, int PF, typename ET>
+__global__ void __launch_bounds__(768) dense_resident_forward_kernel(FwdArgs a) {
+    static_assert(HS % 4 == 0 && WRG % 4 == 0 && WRG <= HS && PF % 2 == 0, "half rows in whole quads");
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int NT = 4 * HS;                   // threads that own a half row: two for each of up to 2*HS targets
+    constexpr int QR = WRG / 4, QL = (HS - WRG) / 4;
+    f32x4* awl = reinterpret_cast<f32x4*>(smem);             // [QL][NT]  the half rows' last QL quads
+    float* dl = reinterpret_cast<float*>(awl + QL * NT);     // [2][2*HS] delta, double-buffered (entries >= S: -inf)
+    VI* tot = reinterpret_cast<VI*>(dl + 4 * HS);
+    const int S = a.S, SP = a.SP, S4 = a.S4, T = a.T, SD = a.SD;
+
+    const int tid = threadIdx.x;
+    const int j = tid >> 1, h = tid & 1;                     // target, half: lanes 2j and 2j+1 share target j
+    const bool tvalid = j < S;
+    const bool writer = tvalid && h == 0;
+    const int song = blockIdx.x;
+    const int Tb = song_length(a.lengths, song, T);
+    const ET* __restrict__ E = reinterpret_cast<const ET*>(a.logE) + (size_t)song * T * S;
+    float* __restrict__ hist = a.hist + (size_t)song * T * SD;
+    const int jc = tvalid ? j : S - 1;
+
+    // ---------------- the half row: quads h*HS/4 .. of row j (quads beyond S4 and idle threads: -inf)
+    const f32x4 ninf4 = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    f32x4 aw[QR];
+    {
+        const f32x4* __restrict__ A4 = reinterpret_cast<const f32x4*>(a.image + a.off_A4);
+        const int q0 = h * (HS / 4);
+#pragma unroll
+        for (int q = 0; q < QR; ++q) aw[q] = (tvalid && q0 + q < S4) ? A4[(size_t)(q0 + q) * SP + j] : ninf4;
+        if (tid < NT) {
+#pragma unroll
+            for (int q = 0; q < QL; ++q) awl[q * NT + tid] = (tvalid && q0 + QR + q < S4) ? A4[(size_t)(q0 + QR + q) * SP + j] : ninf4;
+        }
+    }
+    const int tl = tid < NT ? tid : 0;                       // (threads beyond NT own no target: j >= 2*HS >= S)
+    for (int k = tid; k < 4 * HS; k += blockDim.x) dl[k] = -INFINITY;
+    __syncthreads();
+
+    // ---------------- frame 0
+    {
+        const float d0 = reinterpret_cast<const float*>(a.image + a.off_logpi)[jc] + load_e<ET>(E + jc);
+        if (writer) { hist[j] = d0; dl[j] = d0; }
+    }
+    float er[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) er[k] = load_e<ET>(E + (size_t)(1 + k < Tb ? 1 + k : Tb - 1) * S + jc);
+#pragma unroll
+    for (int q = 0; q < QR; ++q) asm volatile("" ::"v"(aw[q].x), "v"(aw[q].y), "v"(aw[q].z), "v"(aw[q].w));
+    __syncthreads();
+
+    auto frame = [&](const int t, float& e_slot, const int RB) {
+        const f32x4* __restrict__ dcur = reinterpret_cast<const f32x4*>(dl + RB * 2 * HS + h * HS);
+        float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+        auto fold = [&](const f32x4 d, const f32x4 w, float& ma, float& mb) {
+            const f32x2 c0_ = f32x2{d.x, d.y} + f32x2{w.x, w.y};
+            const f32x2 c1_ = f32x2{d.z, d.w} + f32x2{w.z, w.w};
+            ma = fmaxf(fmaxf(ma, c0_.x), c0_.y);
+            mb = fmaxf(fmaxf(mb, c1_.x), c1_.y);
+        };
+        // Reads run one stage ahead of their use and never more: 132 weight registers leave ~16 for data in flight.
+        // Register-resident weights: stages of two delta quads; weights in LDS: stages of one delta quad + its weight quad.
+        {
+            constexpr int NST = (QR + 1) / 2;
+            f32x4 dv[2][2];
+            auto issue = [&](const int c) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (2 * c + u < QR) dv[c & 1][u] = dcur[2 * c + u];
+            };
+            issue(0);
+#pragma unroll
+            for (int c = 0; c < NST; ++c) {
+                if (c + 1 < NST) issue(c + 1);
+                asm volatile("" ::: "memory");
+                fold(dv[c & 1][0], aw[2 * c], m0, m1);
+                if (2 * c + 1 < QR) fold(dv[c & 1][1], aw[2 * c + 1 < QR ? 2 * c + 1 : 0], m2, m3);
+            }
+        }
+        {
+            f32x4 dv[2], wv[2];
+            auto issue = [&](const int c) {
+                dv[c & 1] = dcur[QR + c];
+                wv[c & 1] = awl[c * NT + tl];
+            };
+            if (QL > 0) issue(0);
+#pragma unroll
+            for (int c = 0; c < QL; ++c) {
+                if (c + 1 < QL) issue(c + 1);
+                asm volatile("" ::: "memory");
+                if (c & 1) fold(dv[c & 1], wv[c & 1], m2, m3); else fold(dv[c & 1], wv[c & 1], m0, m1);
+            }
+        }
+        float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+        // the other half of the row: the neighbouring lane (quad_perm [1,0,3,2])
+        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0xB1, 0xf, 0xf, false)));
+        const float dn = m + e_slot;
+        const int tn = t + PF < Tb ? t + PF : Tb - 1;
+        if (writer) {
+            dl[(RB ^ 1) * 2 * HS + j] = dn;
+            hist[(size_t)t * SD + j] = dn;
+        }
+        e_slot = load_e<ET>(E + (size_t)tn * S + jc);
+        __syncthreads();
+    };
+    int t = 1;
+    for (; t + PF - 1 < Tb; t += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) frame(t + k, er[k], k & 1);
+    }
+#pragma unroll
+    for (int k = 0; k < PF - 1; ++k)
+        if (t + k < Tb) frame(t + k, er[k], k & 1);
+
+    const int fb = (Tb - 1) & 1;                             // buffer holding delta_{Tb-1}
+    terminal_argmax(writer ? dl[fb * 2 * HS + j] : -INFINITY, j, writer, tot, (int)(blockDim.x >> 6), a.last_state, a.loglik, song);
+}
+
+// ---------------------------------------------------------------------------------------
 // Step-structured forward kernel (plan.step_ok: the Durrieu matrix of imm's own decoder, S = 722).
 //
 // For voiced source i and voiced target j, logA_T[j][i] = C[min(|i-j| / BW, KB)][i]: column i is piecewise constant in
@@ -2262,7 +2390,23 @@ hipError_t launch_step(const FwdArgs& a, bool f16, hipStream_t st) {
     return hipGetLastError();
 }
 
+// matrix-resident dense kernel: instantiated for half rows of 184 sources (S <= 368); below 257 states the streaming
+// kernel's matrix is small enough for its L1 rate
+bool dense_resident_applies(const FwdArgs& a) { return a.S > 256 && a.S <= 368 && a.dense_form != 1; }
+
+static hipError_t launch_dense_resident(const FwdArgs& a, bool f16, hipStream_t st) {
+    constexpr int HS = 184, WRG = 132, PF = 2;
+    const int threads = (2 * a.S + 63) / 64 * 64;
+    const size_t lds = sizeof(float) * 4 * ((HS - WRG) / 4) * (4 * HS) + sizeof(float) * 4 * HS + sizeof(VI) * 16;
+    if (f16)
+        hipLaunchKernelGGL((dense_resident_forward_kernel<HS, WRG, PF, __half>), dim3((int)a.B), dim3(threads), lds, st, a);
+    else
+        hipLaunchKernelGGL((dense_resident_forward_kernel<HS, WRG, PF, float>), dim3((int)a.B), dim3(threads), lds, st, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_dense(const FwdArgs& a, int ns, bool f16, hipStream_t st) {
+    if (dense_resident_applies(a)) return launch_dense_resident(a, f16, st);
     while (ns > 1 && a.SP > dense_max_threads(ns)) ns >>= 1;
     // one song per workgroup: two threads per target when the workgroup still fits (S <= 512)
     if (ns == 1 && 2 * a.SP <= 1024 && !a.dense_kt1)

@@ -48,6 +48,7 @@ struct FwdArgs {
     int debug;              // timing-only ablation mask; always 0 unless built with -DVIT_TIMING_HOOKS
     int fwd_form;           // banded forward form: 0 by batch size | 1 one target per lane | 2 two targets per lane | 3 scan
     int dense_kt1;          // dense kernel: one thread per target even where two fit
+    int dense_form;         // dense kernel: 0 matrix-resident form where it applies | 1 always the streaming form
     int step_form;          // step kernel: 1 = one target per lane
     size_t off_logpi, off_A4, off_lo, off_kind, off_tabA, off_extraA, off_denseA, off_rowc, off_lo2, off_tabP;
     int pair_ok;            // the plan proved pair windows: use the two-targets-per-lane kernel
