@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 from viterbi_spl_amd import ViterbiDecoder, synth  # noqa: E402
 
 dev = torch.device("cuda:0")
-S, T = 361, 3000
+S, T = (int(sys.argv[1]) if len(sys.argv) > 1 else 361), 3000
 A = synth.dense_random_log_transition(S, seed=3)
 pi = synth.dense_random_log_transition(S, seed=4)[0].copy()
 dec = ViterbiDecoder(A, pi, dev)

@@ -28,7 +28,7 @@ def random_matrix():
         lp = np.log(np.full(n + 1, 1.0 / (n + 1))).astype(np.float32)
         return f"durrieu{n + 1}", la, lp
     if fam == "dense":
-        S = int(rng.integers(2, 200))
+        S = int(rng.choice([rng.integers(2, 200), rng.integers(129, 257), rng.integers(257, 369), rng.integers(369, 420)]))
         la = synth.dense_random_log_transition(S, seed=int(rng.integers(1 << 20)))
         lp = synth.dense_random_log_transition(S, seed=int(rng.integers(1 << 20)))[0].copy()
         return f"dense{S}", la, lp
