@@ -38,6 +38,12 @@ __device__ __forceinline__ float wave_max_f(float x) {
 // peak set with a constant unvoiced logit (`threshold`), every probability divided by its state prior.
 // logits: MODE 0, 2 [n_frames, U]; MODE 1 [n_frames, U+1] with column 0 = unvoiced.  out: [n_frames, U+1].
 // prior (MODE 2): [U+1] in state order (unvoiced last), or null for no scaling.
+//
+// One wave per frame, lane l owns bins l, l+64, ... (coalesced loads and stores, conflict-free LDS).  A bin is a peak when
+// it is the FIRST maximum of its window: c > max(row[b-spw .. b-1]) and c >= max(row[b+1 .. b+spw]).  The two window maxima
+// come from a doubling table in LDS, R_p[i] = max(row[i .. i+p-1]) with p the largest power of two <= spw (two overlapping
+// p-windows cover a window of spw): 3 LDS operations per element and level + 5 reads per bin instead of 2*spw + 1 reads
+// per bin (spw = 15: ~90 instead of ~190 per lane and frame, and no 2-way bank conflicts).
 template <int EPL, int MODE>
 __global__ void __launch_bounds__(kObsWaves * 64) observation_kernel(const float* __restrict__ logits, int64_t n_frames,
                                                                      int U, int spw, double threshold, double offset,
@@ -47,51 +53,106 @@ __global__ void __launch_bounds__(kObsWaves * 64) observation_kernel(const float
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int PW = U + 2 * spw;                       // reflect-padded row
-    float* row = smem + (size_t)wv * (PW + 1);
+    const int PWS = PW + 1;
+    float* row = smem + (size_t)wv * 4 * PWS;          // [4][PWS]: the row, two doubling buffers, per-bin results
+    float* bufA = row + PWS;
+    float* bufB = bufA + PWS;
+    float* aux = bufB + PWS;
     const int in_stride = MODE == 1 ? U + 1 : U;
     const int in_off = MODE == 1 ? 1 : 0;
     const int S = U + 1;
+    int p = 1, levels = 0;
+    while (2 * p <= spw) { p *= 2; ++levels; }
 
-    for (int64_t f = (int64_t)blockIdx.x * kObsWaves + wv; f < n_frames; f += (int64_t)gridDim.x * kObsWaves) {
-        const float* __restrict__ x = logits + f * in_stride + in_off;
-        float* __restrict__ o = out + f * S;
-        // stage the row (coalesced), then the reflect padding: row[spw + i] = x[i]
-        for (int i = lane; i < U; i += 64) row[spw + i] = x[i];
-        if (lane < spw) {
-            row[spw - 1 - lane] = x[lane + 1];                 // x[-k] = x[k]
-            row[spw + U + lane] = x[U - 2 - lane];             // x[U-1+k] = x[U-1-k]
+    const int64_t fstep = (int64_t)gridDim.x * kObsWaves;
+    int64_t f = (int64_t)blockIdx.x * kObsWaves + wv;
+    // the next frame's row is in flight while this one is worked on (a wave handles its frames one after another: without
+    // the prefetch every frame starts with a full HBM round trip)
+    float xn[EPL];
+    float x0n = 0.f;
+    auto fetch = [&](const int64_t fr) {
+        const float* __restrict__ x = logits + fr * in_stride + in_off;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int b = lane + 64 * e;
+            xn[e] = b < U ? x[b] : -INFINITY;
         }
-        // each lane owns bins [lane*EPL, lane*EPL+EPL)
+        if (MODE == 1) x0n = logits[fr * in_stride];
+    };
+    if (f < n_frames) fetch(f);
+    for (; f < n_frames; f += fstep) {
+        float* __restrict__ o = out + f * S;
+        // stage the row, then the reflect padding: row[spw + i] = x[i]
         float xv[EPL];
+        const float x0f = x0n;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int b = lane + 64 * e;
+            xv[e] = xn[e];
+            if (b < U) row[spw + b] = xv[e];
+        }
+        if (f + fstep < n_frames) fetch(f + fstep);
+        asm volatile("" ::: "memory");
+        if (lane < spw) {
+            row[spw - 1 - lane] = row[spw + lane + 1];         // x[-k] = x[k]
+            row[spw + U + lane] = row[spw + U - 2 - lane];     // x[U-1+k] = x[U-1-k]
+        }
+        // doubling: after the loop `src` holds R_p (valid for i <= PW - p).  One wave: its LDS operations execute in program
+        // order, so a level reads what the level before wrote without a barrier (the fences only pin the compiler's order).
+        asm volatile("" ::: "memory");
+        const float* src = row;
+        int w = 1;
+        for (int lv = 0; lv < levels; ++lv) {
+            float* dst = (lv & 1) ? bufB : bufA;
+            for (int i = lane; i + 2 * w <= PW; i += 64) dst[i] = fmaxf(src[i], src[i + w]);
+            asm volatile("" ::: "memory");
+            src = dst;
+            w *= 2;
+        }
         bool pk[EPL];
         float lmax = -INFINITY;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-            const int b = lane * EPL + e;
+            const int b = lane + 64 * e;
             pk[e] = false;
-            xv[e] = -INFINITY;
             if (b < U) {
-                const float c = row[spw + b];
-                bool is = true;                               // FIRST maximum of its window (np.argmax == centre)
-                for (int k = 1; k <= spw; ++k) {
-                    is = is && (c > row[spw + b - k]) && (c >= row[spw + b + k]);
-                }
-                pk[e] = is;
-                xv[e] = c;
-                if (is) lmax = fmaxf(lmax, c);
+                const int c0 = spw + b;                                       // position of the bin in the padded row
+                const float mr = fmaxf(src[c0 + 1], src[c0 + spw - p + 1]);     // max(row[c0+1 .. c0+spw])
+                const float ml = fmaxf(src[c0 - spw], src[c0 - p]);             // max(row[c0-spw .. c0-1])
+                pk[e] = xv[e] > ml && xv[e] >= mr;
+                if (pk[e]) lmax = fmaxf(lmax, xv[e]);
             }
         }
+        // ---- the peaks, compacted: only they need exp / divide / log (a dozen or two per frame), so peak k moves to lane k
+        //      (rank by ballot + popcount, bin index through LDS) and every lane does that arithmetic once per 64 peaks
+        //      instead of once per owned bin
+        asm volatile("" ::: "memory");
+        float* list = bufA;                           // bin index of peak k (as float bits); R_p is no longer needed
+        float* exb = bufB;                            // exp(x - g) of peak k
+        float* res = aux;                             // log-probability by bin (peaks only)
+        int npk = 0;
+        const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const unsigned long long m = __ballot(pk[e]);
+            if (pk[e]) list[npk + __popcll(m & lt)] = __int_as_float(lane + 64 * e);
+            npk += __popcll(m);
+        }
+        asm volatile("" ::: "memory");
         // unvoiced logit: always in the peak set (MODE 2: the padded voicing-threshold logit, rounded to float32 like np.pad)
-        const float x0 = MODE == 1 ? logits[f * in_stride] : (MODE == 2 ? (float)threshold : -INFINITY);
+        const float x0 = MODE == 1 ? x0f : (MODE == 2 ? (float)threshold : -INFINITY);
         float g = wave_max_f(lmax);
         const bool any_peak = g > -INFINITY;
         if (MODE >= 1) g = fmaxf(g, x0);
-        float ex[EPL];
         float lsum = 0.f;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            ex[e] = pk[e] ? expf(xv[e] - g) : 0.f;
-            lsum += ex[e];
+        for (int k0 = 0; k0 < npk; k0 += 64) {
+            const int k = k0 + lane;
+            if (k < npk) {
+                const int b = __float_as_int(list[k]);
+                const float exv = expf(row[spw + b] - g);
+                exb[k] = exv;
+                lsum += exv;
+            }
         }
         float tot = wave_sum(lsum);
         float last;                                                       // probability of the unvoiced state
@@ -100,9 +161,9 @@ __global__ void __launch_bounds__(kObsWaves * 64) observation_kernel(const float
             double pv = 0.0;
             if (any_peak) {
                 const double gd = (double)g;
-                const double s = gd >= threshold ? scale * (gd - threshold) + offset : scale * (gd - threshold) - offset;
-                if (s > 0) pv = 1.0 / (1.0 + exp(-s));
-                else { const double q = exp(s); pv = q / (1.0 + q); }
+                const double s_ = gd >= threshold ? scale * (gd - threshold) + offset : scale * (gd - threshold) - offset;
+                if (s_ > 0) pv = 1.0 / (1.0 + exp(-s_));
+                else { const double q = exp(s_); pv = q / (1.0 + q); }
             }
             t = any_peak ? pv / (double)tot : 0.0;
             last = any_peak ? (float)(1.0 - pv) : 1.f;
@@ -112,19 +173,27 @@ __global__ void __launch_bounds__(kObsWaves * 64) observation_kernel(const float
             t = 1.0;
             last = any_peak ? e0 / tot : 1.f;
         }
+        asm volatile("" ::: "memory");
+        for (int k0 = 0; k0 < npk; k0 += 64) {
+            const int k = k0 + lane;
+            if (k < npk) {
+                const int b = __float_as_int(list[k]);
+                float pr;
+                if (MODE == 0) pr = (float)((double)exb[k] * t);
+                else pr = exb[k] / tot;
+                if (MODE == 2 && prior) pr = pr / prior[b];      // two float32 divisions, like the reference
+                res[b] = logf(pr + kTiny);
+            }
+        }
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-            const int b = lane * EPL + e;
-            if (b < U) {
-                float p;
-                if (MODE == 0) p = (float)((double)ex[e] * t);
-                else p = any_peak ? ex[e] / tot : 0.f;
-                if (MODE == 2 && prior) p = p / prior[b];        // two float32 divisions, like the reference
-                o[b] = pk[e] ? logf(p + kTiny) : kLogTiny;
-            }
+            const int b = lane + 64 * e;
+            if (b < U) o[b] = pk[e] ? res[b] : kLogTiny;
         }
         if (MODE == 2 && prior) last = last / prior[U];          // a peak-less frame: 1 / prior
         if (lane == 0) o[U] = logf(last + kTiny);
+        asm volatile("" ::: "memory");                        // (the next frame's staging must not overtake these reads)
     }
 }
 
@@ -134,8 +203,8 @@ static hipError_t launch_obs(const float* logits, int64_t n_frames, int U, int s
     if (n_frames <= 0) return hipSuccess;
     if (spw < 1 || spw >= U || spw > 64 || U > 768) return hipErrorInvalidValue;
     int64_t blocks = (n_frames + kObsWaves - 1) / kObsWaves;
-    if (blocks > 256 * 8) blocks = 256 * 8;
-    const size_t lds = sizeof(float) * kObsWaves * (U + 2 * spw + 1);
+    if (blocks > 256 * 6) blocks = 256 * 6;       // six workgroups of four frames' LDS fit a CU: one resident wave per frame slot, no second round
+    const size_t lds = sizeof(float) * kObsWaves * 4 * (U + 2 * spw + 1);
     if (U <= 384)
         hipLaunchKernelGGL((observation_kernel<6, MODE>), dim3((int)blocks), dim3(kObsWaves * 64), lds, st, logits, n_frames, U,
                            spw, thr, off, sc, prior, out);
