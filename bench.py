@@ -345,7 +345,7 @@ def main():
         out_k = [(None, None)] * NSLOT
     pending = [None] * NSLOT        # gather handles per slot
     bt_done = [None] * NSLOT        # event: back-trace of the batch in this slot finished
-    s_fwd = torch.cuda.Stream(device=dev)
+    s_fwd = torch.cuda.Stream(device=dev, priority=-1)        # the forward pass is the critical path: its workgroups go first
     s_bt = torch.cuda.Stream(device=dev) if not args.serial else s_fwd
 
     def step(i, ev=None):

@@ -105,7 +105,7 @@ int vit_plan_query(const vit_plan *plan, vit_plan_info *info);
  *                      4 wave form | 5 never the wave form
  *   "backtrace_form"   0 auto | 1 generic kernel | 2 whole-row kernels (no sparse fetch)
  *   "dense_songs"      songs per workgroup of the dense kernel (0 auto); "dense_one_thread" 1 = one thread per target;
- *                      "dense_form" 0 = matrix-resident dense kernel where it applies (128 < S <= 368), 1 = always stream the matrix
+ *                      "dense_form" 0 = matrix-resident dense kernel where it applies (64 < S <= 368), 1 = always stream the matrix
  *   "step_form"        step-structured kernel: 0 four targets per lane, bands split over two waves | 1 one target per lane |
  *                      2 off (plain dense kernel) | 3 four targets per lane, one wave per lane group
  *   "bt_chunks", "bt_warm"   time-parallel back-trace: chunks per song (0 auto), warm-up frames (-1 default)

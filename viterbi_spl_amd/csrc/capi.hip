@@ -21,7 +21,7 @@ struct Tuning {
     int backtrace_form = 0;    // 0 auto | 1 generic (lazy) kernel
     int dense_songs = 0;       // songs per workgroup of the dense kernel (0 = by batch size)
     int dense_one_thread = 0;  // 1: one thread per target in the dense kernel even where two fit
-    int dense_form = 0;        // 0: matrix-resident dense kernel where it applies (128 < S <= 368) | 1: always the streaming kernel
+    int dense_form = 0;        // 0: matrix-resident dense kernel where it applies (64 < S <= 368) | 1: always the streaming kernel
     int step_form = 0;         // step-structured kernel: 0 four targets per lane, split | 1 one | 2 never (plain dense kernel) | 3 four, one wave
     int bt_chunks = 0;         // time-parallel back-trace: chunks per song (0 = auto)
     int bt_warm = -1;          //                            warm-up frames (-1 = default)

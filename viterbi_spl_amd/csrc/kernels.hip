@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(KT == 2 ? 1024 : dense_max_threads(NS)) dense_
 }
 
 // ---------------------------------------------------------------------------------------
-// Dense forward kernel with the matrix RESIDENT on the CU (any matrix, 128 < S <= 368; one song per workgroup).
+// Dense forward kernel with the matrix RESIDENT on the CU (any matrix, 64 < S <= 368; one song per workgroup).
 //
 // dense_forward_kernel streams 4*S*S bytes of transition entries per frame and workgroup through a 64 B/clk vector L1:
 // ~8100 cycles per frame at S = 361, four times the ~2000 its S*S packed adds and maxima take.  But a CU owns 512 KB of
@@ -2390,9 +2390,8 @@ hipError_t launch_step(const FwdArgs& a, bool f16, hipStream_t st) {
     return hipGetLastError();
 }
 
-// matrix-resident dense kernel: instantiated for half rows of 128 and 184 sources (128 < S <= 368); smaller matrices
-// stream fast enough
-bool dense_resident_applies(const FwdArgs& a) { return a.S > 128 && a.S <= 368 && a.dense_form != 1; }
+// matrix-resident dense kernel: instantiated for half rows of 64, 128 and 184 sources (64 < S <= 368)
+bool dense_resident_applies(const FwdArgs& a) { return a.S > 64 && a.S <= 368 && a.dense_form != 1; }
 
 template <int HS, int WRG>
 static hipError_t launch_dense_resident_t(const FwdArgs& a, bool f16, hipStream_t st) {
@@ -2408,6 +2407,7 @@ static hipError_t launch_dense_resident_t(const FwdArgs& a, bool f16, hipStream_
 
 static hipError_t launch_dense_resident(const FwdArgs& a, bool f16, hipStream_t st) {
     // half rows of 128 sources live in registers alone (eight waves); 184 sources: 132 registers + 13 float4 in LDS (twelve waves)
+    if (a.S <= 128) return launch_dense_resident_t<64, 64>(a, f16, st);
     return a.S <= 256 ? launch_dense_resident_t<128, 128>(a, f16, st) : launch_dense_resident_t<184, 132>(a, f16, st);
 }
 
