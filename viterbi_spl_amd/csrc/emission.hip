@@ -104,7 +104,11 @@ __global__ void __launch_bounds__(kObsWaves * 64) observation_kernel(const float
         int w = 1;
         for (int lv = 0; lv < levels; ++lv) {
             float* dst = (lv & 1) ? bufB : bufA;
-            for (int i = lane; i + 2 * w <= PW; i += 64) dst[i] = fmaxf(src[i], src[i + w]);
+#pragma unroll
+            for (int e = 0; e < EPL + 2; ++e) {                   // PW = U + 2*spw <= 64 * (EPL + 2): no loop-carried index arithmetic
+                const int i = lane + 64 * e;
+                if (i + 2 * w <= PW) dst[i] = fmaxf(src[i], src[i + w]);
+            }
             asm volatile("" ::: "memory");
             src = dst;
             w *= 2;
