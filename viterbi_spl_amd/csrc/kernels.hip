@@ -2433,7 +2433,8 @@ hipError_t launch_dense(const FwdArgs& a, int ns, bool f16, hipStream_t st) {
 template <int W, int NWT, typename ET>
 static hipError_t launch_floor_t(const FwdArgs& a, hipStream_t st) {
     constexpr int NP = NWT * 64;
-    constexpr int PF = 4;   // emission rows in flight (2: 13.2 ms, 4: 11.2 ms, 8: 12.4 ms at B = 128)
+    constexpr int PF = W <= 32 ? 12 : 4;   // emission rows in flight: a row is requested PF frames (0.34 us each) before its use; under the overlapped
+                                            // back-trace 4 left ~2 % on the table (B = 128: 4 -> 10.35, 8 -> 10.20, 12 -> 10.12, 16 -> 10.14 ms per forward pass)
     // Up to two songs per CU the one-target-per-lane kernel is (slightly) faster; beyond that the two-targets-per-lane
     // kernel wins because it moves half the window bytes through LDS (B = 512: 14.5 vs 15.5 ms).
     // FwdArgs::fwd_form 1 / 2 force one or the other.
@@ -2441,12 +2442,13 @@ static hipError_t launch_floor_t(const FwdArgs& a, hipStream_t st) {
         const bool pair = a.pair_ok && ((a.B > 256 && a.fwd_form != 1) || a.fwd_form == 2);
         if (pair) {
             constexpr int NPW = (NWT + 1) / 2;
+            constexpr int PFP = 4;             // (two workgroups share a CU here and cover each other's waits: 12 rows in flight measured 9 % slower)
             constexpr int NWMP = (NPW + 3) / 4 * 4;
             const size_t ldsp = sizeof(float) * (8 * (NPW * 128 + 16) + 2 * NWMP + 64 + NWMP) + sizeof(VI) * 16;
             if (W == 32 && a.n_extras == 1)
-                hipLaunchKernelGGL((banded_floor_pair_forward_kernel<W, NPW, (W == 32 ? 1 : -1), PF, ET>), dim3((int)a.B), dim3(NPW * 64), ldsp, st, a);
+                hipLaunchKernelGGL((banded_floor_pair_forward_kernel<W, NPW, (W == 32 ? 1 : -1), PFP, ET>), dim3((int)a.B), dim3(NPW * 64), ldsp, st, a);
             else
-                hipLaunchKernelGGL((banded_floor_pair_forward_kernel<W, NPW, -1, PF, ET>), dim3((int)a.B), dim3(NPW * 64), ldsp, st, a);
+                hipLaunchKernelGGL((banded_floor_pair_forward_kernel<W, NPW, -1, PFP, ET>), dim3((int)a.B), dim3(NPW * 64), ldsp, st, a);
             return hipGetLastError();
         }
     }
