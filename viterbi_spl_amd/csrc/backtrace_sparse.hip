@@ -373,7 +373,9 @@ hipError_t launch_backtrace_sparse(const BtArgs& a, hipStream_t st) {
 // more, shorter chunks than the whole-row kernels: the sparse kernel hides its fetch latency with waves, not with a
 // second tile in registers (sixteen waves per CU at 1024 songs and up)
 int sparse_backtrace_chunks(int64_t B, int T) {
-    long long c = (4 * 1024 + B - 1) / (B > 0 ? B : 1);
+    // (song, chunk) waves up to the resident capacity of the chip (sixteen per CU), never beyond: one wave more starts a second round
+    // and doubles the kernel's time (B = 320: thirteen chunks 2.1 ms, twelve 1.2 ms)
+    long long c = (4 * 1024) / (B > 0 ? B : 1);
     const long long cmax = T / (8 * kBtWarmSparse) > 1 ? T / (8 * kBtWarmSparse) : 1;
     c = c > cmax ? cmax : c;
     c = c > kBtMaxChunks ? kBtMaxChunks : c;
