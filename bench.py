@@ -79,7 +79,7 @@ def forward_kernel_name(dec, algo, B, S):
     info = dec.info
     if algo in ("auto", "banded", "wave", "group") and info["banded_ok"]:
         nwt = next((w for w in (2, 4, 6, 8, 12) if w * 64 >= S), 0)
-        if algo == "wave" or (algo != "group" and info["wave_ok"] and B >= 704):
+        if algo == "wave" or (algo != "group" and info["wave_ok"] and B > 512):
             return "wave_forward_kernel"
         floor_form = info["floor_ok"] and info["n_dense_rows"] == 0 and S < nwt * 64
         if not floor_form:

@@ -64,8 +64,9 @@ inline int hist_stride_ws(const vit_plan* p) {
     return sd > sw ? sd : sw;
 }
 constexpr size_t kMaxStamps = 16;
-constexpr int kWaveMinBatch = 704;   // from here on one song per wavefront beats one song per workgroup (B = 512: 19.4 vs
-                                     // 14.5 ms forward, B = 1024: 20.7 vs 25-27 ms)
+constexpr int kWaveMinBatch = 513;   // from here on one song per wavefront beats one song per workgroup: two workgroups per CU hold 512
+                                     // songs (B = 512: 18.8 vs 14.2 ms forward); the 513th starts a second round (B = 576: 18.8 vs
+                                     // 19.8 ms, B = 1024: 20.0 vs 25-27 ms)
 
 void stamp_put(const vit_plan* p, const FwdStamp& st) {
     std::lock_guard<std::mutex> g(p->mu);
