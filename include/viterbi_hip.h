@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VIT_ABI_VERSION 2
+#define VIT_ABI_VERSION 3
 
 typedef enum vit_status {
     VIT_OK = 0,
@@ -50,7 +50,8 @@ typedef enum vit_status {
     VIT_EHIP = -3,         /* a HIP runtime call failed (see vit_last_hip_error) */
     VIT_EWORKSPACE = -4,   /* workspace smaller than vit_workspace_bytes() */
     VIT_EUNSUPPORTED = -5, /* shape/algorithm combination not supported */
-    VIT_ENOTUPLOADED = -6  /* vit_decode() before vit_plan_upload() */
+    VIT_ENOTUPLOADED = -6, /* vit_decode() before vit_plan_upload() */
+    VIT_ENOFORWARD = -7    /* vit_backtrace() on a workspace without a matching vit_forward() on record */
 } vit_status;
 
 /* storage type of the emission tensor (arithmetic is always float32) */
@@ -103,13 +104,16 @@ int vit_plan_query(const vit_plan *plan, vit_plan_info *info);
  * scripts can reach each kernel form (the library reads NO environment variables).  Keys:
  *   "forward_form"     banded plans: 0 by batch size | 1 one target per lane | 2 two targets per lane | 3 scan form |
  *                      4 wave form | 5 never the wave form
- *   "backtrace_form"   0 auto | 1 generic kernel | 2 whole-row kernels (no sparse fetch)
+ *   "backtrace_form"   0 auto | 1 generic kernel | 2 whole-row kernels (no sparse fetch) | 3 sparse fetch, one (song, chunk)
+ *                      stream per wavefront (auto walks two per wavefront where the band is within 14 sources of the target)
  *   "dense_songs"      songs per workgroup of the dense kernel (0 auto); "dense_one_thread" 1 = one thread per target;
  *                      "dense_form" 0 = matrix-resident dense kernel where it applies (64 < S <= 368), 1 = always stream the matrix
  *   "step_form"        step-structured kernel: 0 four targets per lane, bands split over two waves | 1 one target per lane |
  *                      2 off (plain dense kernel) | 3 four targets per lane, one wave per lane group
  *   "bt_chunks", "bt_warm"   time-parallel back-trace: chunks per song (0 auto), warm-up frames (-1 default)
  *   "win_shift"        LDS window shift 0..3 (-1 from the plan); "wave_min_batch" (0 default), "wave_two" 1
+ *   "wave_history"     wave form: 0 = store the delta rows of even frames only where the plan allows it (the back-trace
+ *                      rebuilds the odd ones; half the history bytes) | 1 = every row | 2 = half, VIT_EUNSUPPORTED otherwise
  *   "timing"           ablation / probe mask: accepted only by a -DVIT_TIMING_HOOKS build (VIT_EUNSUPPORTED otherwise;
  *                      those bits change results)
  *   "reset"            back to the defaults
@@ -126,6 +130,10 @@ int vit_plan_upload(vit_plan *plan, void *device_image, size_t bytes, vit_stream
  * [B,T,SD] + per-song terminals; SD = ceil((S+2)/4)*4 with the per-frame maximum in pad column S, or 64*ceil(S/64) in slot
  * order for the wave form -- the size covers whichever form runs).  256-byte aligned base required. */
 size_t vit_workspace_bytes(const vit_plan *plan, int64_t B, int64_t T);
+/* The same for ONE algo (what vit_forward / vit_decode check a workspace against): smaller than vit_workspace_bytes() where
+ * the chosen kernel keeps a narrower or a half history -- the wave form stores [B, ceil(T/2), 64*ceil(S/64)] floats.  The
+ * answer depends on B (VIT_ALGO_AUTO / _BANDED pick the form by batch size) and on the plan's options; 0 = algo unsupported. */
+size_t vit_workspace_bytes_for(const vit_plan *plan, int64_t B, int64_t T, int algo);
 
 /*
  * Decode B songs.
@@ -144,12 +152,24 @@ int vit_decode(const vit_plan *plan, const void *logE, int emis_dtype, int64_t B
  * of one batch on another stream.  vit_decode() == forward then backtrace.  vit_forward records, per plan and workspace
  * pointer, which kernel family filled the workspace and how its history rows are laid out; vit_backtrace reads that
  * record (its `algo` argument is ignored) and returns VIT_EINVAL when this workspace has no forward pass of the same
- * (B, T) on record.  The caller orders the two calls (same stream, or an event). */
+ * (B, T) on record (VIT_ENOFORWARD).  The caller orders the two calls (same stream, or an event).  A plan keeps the
+ * records of the 64 workspaces most recently written; a failed vit_forward leaves none for its workspace.  The emission
+ * tensor handed to vit_forward must stay valid and unchanged until vit_backtrace has run: a half history (wave form)
+ * re-reads 32 emission values of every odd frame. */
 int vit_forward(const vit_plan *plan, const void *logE, int emis_dtype, int64_t B, int64_t T,
                 const int64_t *lengths, void *workspace, size_t workspace_bytes,
                 float *loglik, int algo, vit_stream stream);
 int vit_backtrace(const vit_plan *plan, int64_t B, int64_t T, const int64_t *lengths,
                   void *workspace, size_t workspace_bytes, int32_t *states, int algo, vit_stream stream);
+
+/* Event counts of the last vit_backtrace() on this workspace (banded plans; all zero for the kernels that do not count):
+ * *offset = byte offset, inside the workspace, of an int32 [B][*n_per_song] device array (valid once the back-trace has run
+ * on its stream): per song [0] tiles fetched, [1] tiles taken from the prefetch, [2] span misses (the path left the fetched
+ * columns), [3] whole-row evaluations (the bound fl(M_t + c_j) could not exclude the row constant), [4] of those: odd rows
+ * of a half history rebuilt in full, [5] chunks repaired by the verify pass, [6] frames rewritten by repairs.  The data-
+ * dependent part of the back-trace's cost; bench.py reports it per 1000 frames. */
+int vit_backtrace_counters(const vit_plan *plan, int64_t B, int64_t T, const void *workspace, size_t *offset,
+                           int32_t *n_per_song);
 
 /* Fused epilogue of Viterbi.__call__ (tonet/for_paper.py:1828-1829):
  * voiced = state < n_bins ; bins = min(state, n_bins-1).  n entries, device pointers.
@@ -194,6 +214,11 @@ int vit_obs_softmax(const float *logits, int64_t n_frames, int32_t n_bins, int32
                     vit_stream stream);
 int vit_obs_softmax_scaled(const float *logits, int64_t n_frames, int32_t n_bins, int32_t spw, double unvoiced_logit,
                            const float *prior, float *logE, vit_stream stream);
+
+/* Self-test hook of the wave-wide DPP scan primitives the kernels are built on (tests/test_gpu_parity.py): vals [n_waves*64]
+ * device float32; mode 0 / 1 ordered (value, index) first-maximum scan forward / reverse, 2 value-only prefix maximum, 3 the
+ * prefix maximum shifted up one lane, 4 wave-wide maximum; out_v / out_i [n_waves*64]. */
+int vit_debug_scan(const float *vals, int n_waves, int mode, float *out_v, int32_t *out_i, vit_stream stream);
 
 #ifdef __cplusplus
 }

@@ -64,7 +64,7 @@ __device__ __forceinline__ float sp_wave_max(float x) {   // kernels.hip wave_ma
 // the bound): 1 for windows up to 59 wide, 2 up to 123 (the jdc band on the 722-state grid: W = 96), 3 for W = 128 (imm).  GT: the per-target
 // candidate table is read from the plan image (L2) instead of LDS -- at S = 722, W = 96 it is 310 KB.
 template <int NWT, bool AFF, int MODE, int KC, bool GT>
-__global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
+__global__ void __launch_bounds__(1024, (GT && KC == 1) ? 8 : 4) sparse_backtrace_kernel(BtArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int EPL = NWT;
     constexpr int kSpNS = sp_span(KC);
@@ -132,43 +132,71 @@ __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
     const int lo_max = S - W;
     const int c0_max = (SD - kSpNS) & ~3;    // (rows are 16-byte aligned; the clamp may leave the last span 16-byte aligned only)
 
+    // Tile I/O in two halves so that the NEXT tile's loads can be in flight while this one is walked (MODE 0): the kernel
+    // waited for HBM once per tile -- ~60 % of a wave's cycles in SQ_WAIT_ANY at B = 1024 (profiles/r02_pmc_B1024_wave_sparse.txt),
+    // most of it the ~2-3 us of this fetch spread over sixteen decisions.  The prefetch keeps the columns of the current tile (the
+    // best guess for a slowly moving path); if the path has left them by the time the tile is due, it is fetched again, centred.
+    auto tile_load = [&](const int first, const int rows, const int c0, f32x4 (&stage)[kSpVec], float (&auxv)[2]) {
+#pragma unroll
+        for (int v = 0; v < kSpVec; ++v) {
+            const int idx = lane + 64 * v;
+            int r = idx / (kSpNS / 4);
+            const int q = idx % (kSpNS / 4);
+            r = r < rows ? r : rows - 1;
+            stage[v] = *reinterpret_cast<const f32x4*>(hist + (size_t)(first + r) * SD + c0 + 4 * q);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int r = (lane >> 3) + 8 * h;
+            r = r < rows ? r : rows - 1;
+            auxv[h] = hist[(size_t)(first + r) * SD + aux_col];
+        }
+    };
+    auto tile_store = [&](const f32x4 (&stage)[kSpVec], const float (&auxv)[2]) {
+#pragma unroll
+        for (int v = 0; v < kSpVec; ++v) {
+            const int idx = lane + 64 * v;
+            *reinterpret_cast<f32x4*>(tile + (idx / (kSpNS / 4)) * kSpRS + 4 * (idx % (kSpNS / 4))) = stage[v];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) tile[((lane >> 3) + 8 * h) * kSpRS + kSpNS + aux_e] = auxv[h];
+    };
+    constexpr bool kPrefetch = MODE == 0;
+    int n_tiles = 0, n_pref = 0, n_miss = 0, n_full = 0, n_rep = 0, n_repf = 0;      // event counts of this wave (scalar registers)
+
     // chase(top, bottom, cur, write): decide the states of frames top .. bottom (descending) from the delta rows
     // top .. bottom, starting from state `cur` at frame top+1.
     auto chase = [&](int top, const int bottom, int cur, const bool write) -> int {
+        f32x4 pf_stage[kSpVec];
+        float pf_aux[2];
+        int pf_top = -1, pf_c0 = 0;              // tile in flight: rows pf_top - kSpK + 1 (clipped at bottom) .. pf_top, columns pf_c0 ..
         while (top >= bottom) {
             cur = __builtin_amdgcn_readfirstlane(cur);
             const int first = top - kSpK + 1 > bottom ? top - kSpK + 1 : bottom;
             const int rows = top - first + 1;
-            // ---- fetch the tile: span columns [c0, c0 + NS) of rows first .. top, centred on the window of `cur`
+            // ---- the tile: span columns [c0, c0 + NS) of rows first .. top, centred on the window of `cur`
             int lo_c;
             if (AFF) { lo_c = cur - a.lo_off; lo_c = lo_c < 0 ? 0 : (lo_c > lo_max ? lo_max : lo_c); }
             else lo_c = __builtin_amdgcn_readfirstlane(loL[cur]);
             int c0 = (a.col0 + lo_c - (kSpNS - W) / 4) & ~15;      // 64-byte aligned: the span touches 2.5 lines of 128 B on average instead of 2.9
             c0 = c0 < 0 ? 0 : (c0 > c0_max ? c0_max : c0);
-            {
+            if (kPrefetch && pf_top == top && a.col0 + lo_c - pf_c0 >= 0 && a.col0 + lo_c - pf_c0 + W <= kSpNS) {
+                c0 = pf_c0;
+                tile_store(pf_stage, pf_aux);
+                ++n_pref;
+            } else {
+                ++n_tiles;
                 f32x4 stage[kSpVec];
                 float auxv[2];
-#pragma unroll
-                for (int v = 0; v < kSpVec; ++v) {
-                    const int idx = lane + 64 * v;
-                    int r = idx / (kSpNS / 4);
-                    const int q = idx % (kSpNS / 4);
-                    r = r < rows ? r : rows - 1;
-                    stage[v] = *reinterpret_cast<const f32x4*>(hist + (size_t)(first + r) * SD + c0 + 4 * q);
-                }
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    int r = (lane >> 3) + 8 * h;
-                    r = r < rows ? r : rows - 1;
-                    auxv[h] = hist[(size_t)(first + r) * SD + aux_col];
-                }
-#pragma unroll
-                for (int v = 0; v < kSpVec; ++v) {
-                    const int idx = lane + 64 * v;
-                    *reinterpret_cast<f32x4*>(tile + (idx / (kSpNS / 4)) * kSpRS + 4 * (idx % (kSpNS / 4))) = stage[v];
-                }
-#pragma unroll
-                for (int h = 0; h < 2; ++h) tile[((lane >> 3) + 8 * h) * kSpRS + kSpNS + aux_e] = auxv[h];
+                tile_load(first, rows, c0, stage, auxv);
+                tile_store(stage, auxv);
+            }
+            pf_top = -1;
+            if (kPrefetch && first - 1 >= bottom) {
+                pf_top = first - 1;
+                pf_c0 = c0;
+                const int nfirst = pf_top - kSpK + 1 > bottom ? pf_top - kSpK + 1 : bottom;
+                tile_load(nfirst, pf_top - nfirst + 1, c0, pf_stage, pf_aux);
             }
             int outv = 0;
             const int oldv = (MODE == 1 && lane < rows) ? states[first + lane] : -1;
@@ -180,7 +208,7 @@ __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
                 if (AFF) { lo = cur - a.lo_off; lo = lo < 0 ? 0 : (lo > lo_max ? lo_max : lo); }
                 else lo = __builtin_amdgcn_readfirstlane(loL[cur]);
                 const int wlo = a.col0 + lo - c0;                       // window start inside the span
-                if (wlo < 0 || wlo + W > kSpNS) { rmiss = r; break; }
+                if (wlo < 0 || wlo + W > kSpNS) { rmiss = r; ++n_miss; break; }
                 const float* trow = tile + r * kSpRS;
                 float v[KC], av[KC];
 #pragma unroll
@@ -228,6 +256,7 @@ __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
                 if (mf < m) {
                     idx = lowest_candidate(m);
                 } else {
+                    ++n_full;
                     // ---- full evaluation, straight from the history row in global memory: every source outside the
                     //      window / extra columns contributes fl(delta_t[i] + c_cur)
                     const float* __restrict__ grow = hist + (size_t)(first + r) * SD + a.col0;
@@ -257,6 +286,7 @@ __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
             }
             const int rkeep = rstop > rmiss ? rstop : rmiss;     // rows above rkeep were decided in this pass
             if (write && lane < rows && lane > rkeep) states[first + lane] = outv;
+            if (MODE == 1) n_repf += rows - 1 - rkeep;
             if (MODE == 1 && rstop >= 0) return __builtin_amdgcn_readfirstlane(states[bottom]);   // the stored path continues unchanged
             top = rmiss >= 0 ? first + rmiss : first - 1;
         }
@@ -308,11 +338,21 @@ __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
             if (truth < 0) truth = __builtin_amdgcn_readfirstlane(states[hi_c]);
             const int assumed = __builtin_amdgcn_readfirstlane(a.entry[(size_t)song * C + c]);
             if (hi_c > lo_c && assumed != truth) {
+                ++n_rep;
                 truth = chase(hi_c - 1, lo_c, truth, true);   // re-chase from the true state; ends at frame lo_c
             } else {
                 truth = -1;                       // chunk c stands: its frame lo_c is already in `states`
             }
         }
+    }
+    if (lane == 0 && a.counters) {
+        int32_t* ct = a.counters + (size_t)song * kBtCounters;
+        if (n_tiles) atomicAdd(ct + kCtTiles, n_tiles);
+        if (n_pref) atomicAdd(ct + kCtPrefetched, n_pref);
+        if (n_miss) atomicAdd(ct + kCtMisses, n_miss);
+        if (n_full) atomicAdd(ct + kCtFullRows, n_full);
+        if (n_rep) atomicAdd(ct + kCtRepairs, n_rep);
+        if (n_repf) atomicAdd(ct + kCtRepairFrames, n_repf);
     }
 }
 
@@ -334,40 +374,43 @@ bool sparse_backtrace_applies(const BtArgs& a) {
 }
 
 template <int NWT, bool AFF, int KC, bool GT>
-static hipError_t launch_sparse_t(const BtArgs& a, hipStream_t st) {
+static hipError_t launch_sparse_t(const BtArgs& a, hipStream_t st, int phases) {
     int nw = 16;
     while (nw > 4 && sparse_lds_bytes(a, nw, !GT) + 1024 > 160 * 1024) nw >>= 1;
     const size_t lds = sparse_lds_bytes(a, nw, !GT);
     const long long waves0 = (long long)a.B * a.chunks;
-    hipLaunchKernelGGL((sparse_backtrace_kernel<NWT, AFF, 0, KC, GT>), dim3((int)((waves0 + nw - 1) / nw)), dim3(nw * 64), lds, st, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess || a.chunks <= 1) return e;
+    hipError_t e = hipSuccess;
+    if (phases & 1) {
+        hipLaunchKernelGGL((sparse_backtrace_kernel<NWT, AFF, 0, KC, GT>), dim3((int)((waves0 + nw - 1) / nw)), dim3(nw * 64), lds, st, a);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess || a.chunks <= 1 || !(phases & 2)) return e;
     hipLaunchKernelGGL((sparse_backtrace_kernel<NWT, AFF, 1, KC, GT>), dim3((int)((a.B + nw - 1) / nw)), dim3(nw * 64), lds, st, a);
     return hipGetLastError();
 }
 
 template <int NWT>
-static hipError_t launch_sparse_a(const BtArgs& a, hipStream_t st) {
-    const bool gt = !sparse_table_fits(a);
+static hipError_t launch_sparse_a(const BtArgs& a, hipStream_t st, int phases) {
+    const bool gt = !sparse_table_fits(a) || a.bt_form == 4;
     if (sparse_kc(a) == 1) {
-        if (gt) return a.lo_affine ? launch_sparse_t<NWT, true, 1, true>(a, st) : launch_sparse_t<NWT, false, 1, true>(a, st);
-        return a.lo_affine ? launch_sparse_t<NWT, true, 1, false>(a, st) : launch_sparse_t<NWT, false, 1, false>(a, st);
+        if (gt) return a.lo_affine ? launch_sparse_t<NWT, true, 1, true>(a, st, phases) : launch_sparse_t<NWT, false, 1, true>(a, st, phases);
+        return a.lo_affine ? launch_sparse_t<NWT, true, 1, false>(a, st, phases) : launch_sparse_t<NWT, false, 1, false>(a, st, phases);
     }
     if (sparse_kc(a) == 2) {
-        if (gt) return a.lo_affine ? launch_sparse_t<NWT, true, 2, true>(a, st) : launch_sparse_t<NWT, false, 2, true>(a, st);
-        return a.lo_affine ? launch_sparse_t<NWT, true, 2, false>(a, st) : launch_sparse_t<NWT, false, 2, false>(a, st);
+        if (gt) return a.lo_affine ? launch_sparse_t<NWT, true, 2, true>(a, st, phases) : launch_sparse_t<NWT, false, 2, true>(a, st, phases);
+        return a.lo_affine ? launch_sparse_t<NWT, true, 2, false>(a, st, phases) : launch_sparse_t<NWT, false, 2, false>(a, st, phases);
     }
-    if (gt) return a.lo_affine ? launch_sparse_t<NWT, true, 3, true>(a, st) : launch_sparse_t<NWT, false, 3, true>(a, st);
-    return a.lo_affine ? launch_sparse_t<NWT, true, 3, false>(a, st) : launch_sparse_t<NWT, false, 3, false>(a, st);
+    if (gt) return a.lo_affine ? launch_sparse_t<NWT, true, 3, true>(a, st, phases) : launch_sparse_t<NWT, false, 3, true>(a, st, phases);
+    return a.lo_affine ? launch_sparse_t<NWT, true, 3, false>(a, st, phases) : launch_sparse_t<NWT, false, 3, false>(a, st, phases);
 }
 
-hipError_t launch_backtrace_sparse(const BtArgs& a, hipStream_t st) {
+hipError_t launch_backtrace_sparse(const BtArgs& a, hipStream_t st, int phases) {
     const int nwt = (a.S + 63) / 64;
-    if (nwt <= 2) return launch_sparse_a<2>(a, st);
-    if (nwt <= 4) return launch_sparse_a<4>(a, st);
-    if (nwt <= 6) return launch_sparse_a<6>(a, st);
-    if (nwt <= 8) return launch_sparse_a<8>(a, st);
-    return launch_sparse_a<12>(a, st);
+    if (nwt <= 2) return launch_sparse_a<2>(a, st, phases);
+    if (nwt <= 4) return launch_sparse_a<4>(a, st, phases);
+    if (nwt <= 6) return launch_sparse_a<6>(a, st, phases);
+    if (nwt <= 8) return launch_sparse_a<8>(a, st, phases);
+    return launch_sparse_a<12>(a, st, phases);
 }
 
 // more, shorter chunks than the whole-row kernels: the sparse kernel hides its fetch latency with waves, not with a

@@ -18,7 +18,7 @@
 struct Tuning {
     int forward_form = 0;      // banded plans: 0 by batch size | 1 one target per lane | 2 two targets per lane | 3 scan form
                                //               | 4 wave form (one song per wavefront) | 5 never the wave form
-    int backtrace_form = 0;    // 0 auto | 1 generic (lazy) kernel
+    int backtrace_form = 0;    // 0 auto | 1 generic (lazy) kernel | 2 whole-row kernels | 3 sparse fetch with one stream per wave (no half-wave pass)
     int dense_songs = 0;       // songs per workgroup of the dense kernel (0 = by batch size)
     int dense_one_thread = 0;  // 1: one thread per target in the dense kernel even where two fit
     int dense_form = 0;        // 0: matrix-resident dense kernel where it applies (64 < S <= 368) | 1: always the streaming kernel
@@ -27,7 +27,9 @@ struct Tuning {
     int bt_warm = -1;          //                            warm-up frames (-1 = default)
     int win_shift = -1;        // LDS window shift of the floor kernels (-1 = from the plan)
     int wave_min_batch = 0;    // batch size from which banded plans take the wave form (0 = default)
-    int wave_two = 0;          // 1: always the two-waves-per-SIMD instantiation of the wave kernel
+    int wave_two = 0;          // wave kernel: 1 always the 256-register instantiation (the default but for two extra columns) | 2 the 512-register
+                               // one up to 1024 songs
+    int wave_history = 0;      // wave form: 0 half history (even rows) where the plan allows it | 1 every row | 2 half, or VIT_EUNSUPPORTED
     int timing = 0;
 };
 
@@ -38,6 +40,9 @@ struct FwdStamp {
     int family = 0;            // 1 dense / step, 2 banded (one song per workgroup), 3 wave
     int SD = 0, col0 = 0, mcol = 0, xcol0 = -1;
     int have_fmax = 0;         // column mcol of every history row holds a bound on max_i delta_t[i]
+    int half = 0;              // wave form, even rows only: the back-trace re-reads the emissions
+    const void* logE = nullptr;
+    int e_f16 = 0;
 };
 
 struct vit_plan {
@@ -63,15 +68,19 @@ inline int hist_stride_ws(const vit_plan* p) {
     const int sw = (p->bp.ok && p->bp.wave_ok) ? vit::wave_hist_stride(p->bp.wave_npl) : 0;
     return sd > sw ? sd : sw;
 }
-constexpr size_t kMaxStamps = 16;
+constexpr size_t kMaxStamps = 64;    // workspaces with a forward pass on record per plan (include/viterbi_hip.h, vit_forward)
 constexpr int kWaveMinBatch = 513;   // from here on one song per wavefront beats one song per workgroup: two workgroups per CU hold 512
                                      // songs (B = 512: 18.8 vs 14.2 ms forward); the 513th starts a second round (B = 576: 18.8 vs
                                      // 19.8 ms, B = 1024: 20.0 vs 25-27 ms)
 
-void stamp_put(const vit_plan* p, const FwdStamp& st) {
+void stamp_erase(const vit_plan* p, const void* ws) {
     std::lock_guard<std::mutex> g(p->mu);
     for (size_t k = 0; k < p->stamps.size(); ++k)
-        if (p->stamps[k].ws == st.ws) { p->stamps.erase(p->stamps.begin() + k); break; }
+        if (p->stamps[k].ws == ws) { p->stamps.erase(p->stamps.begin() + k); break; }
+}
+void stamp_put(const vit_plan* p, const FwdStamp& st) {
+    stamp_erase(p, st.ws);
+    std::lock_guard<std::mutex> g(p->mu);
     p->stamps.insert(p->stamps.begin(), st);
     if (p->stamps.size() > kMaxStamps) p->stamps.pop_back();
 }
@@ -91,21 +100,49 @@ struct WsLayout {
     size_t off_hist, off_fmax, off_last, off_entry, bytes;
 };
 
-WsLayout ws_layout(const vit_plan* p, int64_t B, int64_t T) {
+// history floats per song: `rows` rows of `stride` floats
+WsLayout ws_layout_hist(int64_t B, size_t rows, size_t stride) {
     WsLayout w;
     w.off_hist = 0;
-    w.off_fmax = align256((size_t)B * (size_t)T * hist_stride_ws(p) * sizeof(float));
+    w.off_fmax = align256((size_t)B * rows * stride * sizeof(float));
     w.off_last = w.off_fmax + align256((size_t)B * 64 * sizeof(float));   // timing-experiment scratch
     w.off_entry = w.off_last + align256((size_t)B * sizeof(int32_t));
     w.bytes = w.off_entry + align256((size_t)B * vit::kBtMaxChunks * sizeof(int32_t));
     return w;
 }
+// the layout that covers every forward kernel of the plan (vit_workspace_bytes)
+WsLayout ws_layout(const vit_plan* p, int64_t B, int64_t T) { return ws_layout_hist(B, (size_t)T, (size_t)hist_stride_ws(p)); }
 
-int check_common(const vit_plan* plan, int64_t B, int64_t T, const void* ws, size_t ws_bytes) {
+// Does the wave form of this plan store a half history (even frames only)?  The back-trace kernel for it
+// (backtrace_half.hip) is asked with the layout the forward kernel would write.
+bool wave_half_applies(const vit_plan* p, int64_t T) {
+    if (!(p->bp.ok && p->bp.wave_ok) || p->tune.wave_history == 1 || T < 2) return false;
+    vit::BtArgs b{};
+    b.S = p->S;
+    b.SP = p->L.SP;
+    b.SD = vit::wave_hist_stride(p->bp.wave_npl);
+    b.col0 = b.SD - p->S;
+    b.W = p->bp.W;
+    b.banded = 1;
+    b.n_extras = p->bp.n_extras;
+    b.n_dense = p->bp.n_dense;
+    b.lo_affine = p->bp.lo_affine ? 1 : 0;
+    b.lo_off = p->bp.lo_off;
+    return vit::half_backtrace_applies(b);
+}
+// the layout of one forward family (1 dense / step, 2 banded workgroup kernels, 3 wave)
+WsLayout ws_layout_family(const vit_plan* p, int family, int64_t B, int64_t T) {
+    if (family == 3) {
+        const size_t sd = (size_t)vit::wave_hist_stride(p->bp.wave_npl);
+        return wave_half_applies(p, T) ? ws_layout_hist(B, (size_t)((T + 1) / 2), sd) : ws_layout_hist(B, (size_t)T, sd);
+    }
+    return ws_layout_hist(B, (size_t)T, (size_t)hist_stride(p->S));
+}
+
+int check_common(const vit_plan* plan, int64_t B, int64_t T, const void* ws) {
     if (!plan || !ws) return VIT_EINVAL;
     if (B < 0 || T < 1 || T > (int64_t)1 << 30 || B > (int64_t)1 << 30) return VIT_EINVAL;
     if (!plan->dev_image) return VIT_ENOTUPLOADED;
-    if (ws_bytes < ws_layout(plan, B, T).bytes) return VIT_EWORKSPACE;
     if (((uintptr_t)ws & 255) != 0) return VIT_EINVAL;
     return VIT_OK;
 }
@@ -125,6 +162,7 @@ const char* vit_status_string(int status) {
         case VIT_EWORKSPACE: return "workspace too small";
         case VIT_EUNSUPPORTED: return "unsupported shape or algorithm";
         case VIT_ENOTUPLOADED: return "plan image not uploaded";
+        case VIT_ENOFORWARD: return "no forward pass on record for this workspace";
         default: return "unknown status";
     }
 }
@@ -196,6 +234,7 @@ static int* tuning_field(Tuning& t, const char* key) {
         {"dense_songs", &Tuning::dense_songs}, {"dense_one_thread", &Tuning::dense_one_thread}, {"dense_form", &Tuning::dense_form},
         {"step_form", &Tuning::step_form}, {"bt_chunks", &Tuning::bt_chunks}, {"bt_warm", &Tuning::bt_warm},
         {"win_shift", &Tuning::win_shift}, {"wave_min_batch", &Tuning::wave_min_batch}, {"wave_two", &Tuning::wave_two},
+        {"wave_history", &Tuning::wave_history},
         {"timing", &Tuning::timing},
     };
     for (const auto& e : tab)
@@ -233,19 +272,30 @@ static int resolve_family(const vit_plan* plan, int algo, int64_t B) {
     return algo == VIT_ALGO_AUTO ? 1 : VIT_EUNSUPPORTED;
 }
 
+size_t vit_workspace_bytes_for(const vit_plan* plan, int64_t B, int64_t T, int algo) {
+    if (!plan || B < 0 || T < 1) return 0;
+    const int family = resolve_family(plan, algo, B);
+    if (family < 0) return 0;
+    return ws_layout_family(plan, family, B, T).bytes;
+}
+
 int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t B, int64_t T,
                 const int64_t* lengths, void* workspace, size_t workspace_bytes, float* loglik, int algo,
                 vit_stream stream) {
-    int rc = check_common(plan, B, T, workspace, workspace_bytes);
+    int rc = check_common(plan, B, T, workspace);
     if (rc != VIT_OK) return rc;
     if (!logE) return VIT_EINVAL;
     if (emis_dtype != VIT_F32 && emis_dtype != VIT_F16) return VIT_EINVAL;
     const int family = resolve_family(plan, algo, B);
     if (family < 0) return family;
-    if (B == 0) return VIT_OK;
     const Tuning& tn = plan->tune;
+    const bool half = family == 3 && wave_half_applies(plan, T);
+    if (family == 3 && tn.wave_history == 2 && !half) return VIT_EUNSUPPORTED;
+    const WsLayout w = ws_layout_family(plan, family, B, T);
+    if (workspace_bytes < w.bytes) return VIT_EWORKSPACE;
+    if (B == 0) return VIT_OK;
+    stamp_erase(plan, workspace);      // whatever this workspace held is gone once the kernel below starts; re-stamped on success
 
-    const WsLayout w = ws_layout(plan, B, T);
     uint8_t* ws = static_cast<uint8_t*>(workspace);
     vit::FwdArgs a{};
     a.image = plan->dev_image;
@@ -293,7 +343,9 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
     a.wave_ok = plan->bp.ok && plan->bp.wave_ok ? 1 : 0;
     a.wave_npl = plan->bp.wave_npl;
     a.wave_dk = plan->bp.wave_dk;
-    a.wave_flags = tn.wave_two ? 1 : 0;
+    a.wave_flags = tn.wave_two == 1 ? 1 : (tn.wave_two == 2 ? 2 : 0);
+    a.hist_half = half ? 1 : 0;
+    a.hist_rows = half ? (T + 1) / 2 : T;
     a.win_shift = (plan->bp.ok && plan->bp.lo_affine) ? (plan->bp.lo_off & 3) : 0;
     a.win_shift2 = (plan->bp.ok && plan->bp.pair_ok && plan->bp.lo2_affine) ? (plan->bp.lo2_off & 3) : 0;
     if (tn.win_shift >= 0) a.win_shift = a.win_shift2 = tn.win_shift & 3;   // every value is functionally correct
@@ -314,6 +366,9 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
         st.mcol = 0;
         st.xcol0 = 1;
         st.have_fmax = 1;
+        st.half = half ? 1 : 0;
+        st.logE = logE;
+        st.e_f16 = emis_dtype == VIT_F16 ? 1 : 0;
         e = vit::launch_wave(a, emis_dtype == VIT_F16, (hipStream_t)stream);
     } else if (family == 2) {
         e = vit::launch_banded(a, emis_dtype == VIT_F16, (hipStream_t)stream);
@@ -333,15 +388,16 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
 
 int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* lengths, void* workspace,
                   size_t workspace_bytes, int32_t* states, int algo, vit_stream stream) {
-    int rc = check_common(plan, B, T, workspace, workspace_bytes);
+    int rc = check_common(plan, B, T, workspace);
     if (rc != VIT_OK) return rc;
     if (!states) return VIT_EINVAL;
     (void)algo;   // kept for ABI compatibility: the layout comes from what vit_forward recorded for this workspace
     if (B == 0) return VIT_OK;
     FwdStamp st;
-    if (!stamp_get(plan, workspace, &st) || st.B != B || st.T != T) return VIT_EINVAL;   // no matching vit_forward
+    if (!stamp_get(plan, workspace, &st) || st.B != B || st.T != T) return VIT_ENOFORWARD;   // no matching vit_forward
     const Tuning& tn = plan->tune;
-    const WsLayout w = ws_layout(plan, B, T);
+    const WsLayout w = st.half ? ws_layout_hist(B, (size_t)((T + 1) / 2), (size_t)st.SD) : ws_layout_hist(B, (size_t)T, (size_t)st.SD);
+    if (workspace_bytes < w.bytes) return VIT_EWORKSPACE;
     uint8_t* ws = static_cast<uint8_t*>(workspace);
     vit::BtArgs b{};
     b.image = plan->dev_image;
@@ -387,7 +443,44 @@ int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* len
     b.off_Arow = plan->L.off_Arow;
     b.off_rowc = plan->L.off_rowc;
     if (st.family == 3 && !(b.banded && b.n_dense == 0)) return VIT_EINVAL;   // (cannot happen: wave_ok implies both)
-    const bool sparse = b.bt_form == 0 && vit::sparse_backtrace_applies(b);
+    b.hist_rows = T;
+    b.counters = nullptr;
+    if ((size_t)B * vit::kBtCounters * sizeof(int32_t) <= align256((size_t)B * 64 * sizeof(float))) {
+        b.counters = reinterpret_cast<int32_t*>(ws + w.off_fmax);     // the per-song scratch: event counts of this back-trace
+        hipError_t ez = hipMemsetAsync(b.counters, 0, (size_t)B * vit::kBtCounters * sizeof(int32_t), (hipStream_t)stream);
+        if (ez != hipSuccess) return hip_fail(ez);
+    }
+    b.pair_ok = vit::pair_backtrace_plan_ok(plan->bp) ? 1 : 0;
+    b.off_tabH = plan->L.off_tabH;
+    if (st.half) {
+        b.hist_half = 1;
+        b.hist_rows = (T + 1) / 2;
+        b.mcol_odd = 1 + b.n_extras;
+        b.xcol0_odd = 2 + b.n_extras;
+        b.logE = st.logE;
+        b.e_f16 = st.e_f16;
+    }
+    // speculative pass with two (song, chunk) streams per wave where the band allows it, then the verify-and-repair pass of the
+    // one-stream kernel for this history layout
+    if (b.bt_form == 0 && vit::pair_backtrace_applies(b) && (st.half ? vit::half_backtrace_applies(b) : vit::sparse_backtrace_applies(b))) {
+        b.chunks = vit::pair_backtrace_chunks(B, (int)T);
+        b.warm = vit::kBtWarmSparse;
+        if (tn.bt_chunks >= 1 && tn.bt_chunks <= vit::kBtMaxChunks) b.chunks = tn.bt_chunks;
+        if (tn.bt_warm >= 0) b.warm = tn.bt_warm;
+        hipError_t ep = vit::launch_backtrace_pair(b, (hipStream_t)stream);
+        if (ep == hipSuccess && b.chunks > 1)
+            ep = st.half ? vit::launch_backtrace_half(b, (hipStream_t)stream, 2) : vit::launch_backtrace_sparse(b, (hipStream_t)stream, 2);
+        return ep == hipSuccess ? VIT_OK : hip_fail(ep);
+    }
+    if (st.half) {
+        b.chunks = vit::sparse_backtrace_chunks(B, (int)T);
+        b.warm = vit::kBtWarmSparse;
+        if (tn.bt_chunks >= 1 && tn.bt_chunks <= vit::kBtMaxChunks) b.chunks = tn.bt_chunks;
+        if (tn.bt_warm >= 0) b.warm = tn.bt_warm;
+        hipError_t eh = vit::launch_backtrace_half(b, (hipStream_t)stream);
+        return eh == hipSuccess ? VIT_OK : hip_fail(eh);
+    }
+    const bool sparse = (b.bt_form == 0 || b.bt_form == 3 || b.bt_form == 4) && vit::sparse_backtrace_applies(b);
     b.chunks = sparse ? vit::sparse_backtrace_chunks(B, (int)T) : vit::backtrace_chunks(B, (int)T);
     b.warm = sparse ? vit::kBtWarmSparse : vit::kBtWarm;
     // test hooks (vit_plan_set_option): force the chunking / warm-up so that the verify-and-repair pass is exercised
@@ -395,6 +488,16 @@ int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* len
     if (tn.bt_warm >= 0) b.warm = tn.bt_warm;
     hipError_t e = vit::launch_backtrace(b, (hipStream_t)stream);
     return e == hipSuccess ? VIT_OK : hip_fail(e);
+}
+
+int vit_backtrace_counters(const vit_plan* plan, int64_t B, int64_t T, const void* workspace, size_t* offset, int32_t* n_per_song) {
+    if (!plan || !workspace || !offset || !n_per_song) return VIT_EINVAL;
+    FwdStamp st;
+    if (!stamp_get(plan, workspace, &st) || st.B != B || st.T != T) return VIT_ENOFORWARD;
+    const WsLayout w = st.half ? ws_layout_hist(B, (size_t)((T + 1) / 2), (size_t)st.SD) : ws_layout_hist(B, (size_t)T, (size_t)st.SD);
+    *offset = w.off_fmax;
+    *n_per_song = vit::kBtCounters;
+    return VIT_OK;
 }
 
 int vit_decode(const vit_plan* plan, const void* logE, int emis_dtype, int64_t B, int64_t T,
@@ -452,7 +555,7 @@ int vit_voicing_notes(const int32_t* states, int64_t n, int32_t n_bins, const fl
     return e == hipSuccess ? VIT_OK : hip_fail(e);
 }
 
-/* not part of the public header: DPP scan self-test used by tests/test_gpu_parity.py */
+/* DPP scan self-test used by tests/test_gpu_parity.py */
 int vit_debug_scan(const float* vals, int n_waves, int mode, float* out_v, int32_t* out_i, vit_stream stream) {
     if (!vals || !out_v || !out_i || n_waves < 1) return VIT_EINVAL;
     hipError_t e = vit::launch_scan_selftest(vals, n_waves, mode, out_v, out_i, (hipStream_t)stream);

@@ -59,7 +59,9 @@ struct FwdArgs {
     int win_shift2;         // the same for the pair windows of banded_floor_pair_forward_kernel
     size_t off_tabV;        // wave form (wave.hip)
     int wave_ok, wave_npl, wave_dk;
-    int wave_flags;         // bit 0: force the two-waves-per-SIMD instantiation
+    int wave_flags;         // bit 0: force the 256-register (two waves per SIMD) instantiation, bit 1: the 512-register one up to 1024 songs
+    int hist_half;          // wave form: 1 = only the delta rows of even frames are stored (wave.hip, HM 1)
+    int64_t hist_rows;      // history rows per song: T, or (T + 1) / 2 with hist_half
     int win_shift;          // 0..3: delta is stored shifted by this many floats in LDS so that the window starts of a
                             // 16-lane group are 16-byte aligned in the SAME copy order (bank-conflict-free b128 reads)
 };
@@ -78,7 +80,8 @@ struct BtArgs {
     int chunks, warm;       // time-parallel back-trace: chunks per song, warm-up frames
     int banded;             // 1: row structure (window / c0 / extras / dense rows) proven by the plan
     int have_fmax;          // the forward pass was a banded kernel (it fills pad column S of the history rows)
-    int bt_form;            // 0 auto (sparse fetch where it applies) | 1 generic (lazy) kernel | 2 whole-row kernels
+    int bt_form;            // 0 auto (two streams per wave, else sparse fetch, where they apply) | 1 generic (lazy) kernel | 2 whole-row kernels
+                            // | 3 sparse fetch, one stream per wave
     int lo_affine, lo_off;  // lo[j] == clamp(j - lo_off, 0, S - W)
     int dense_rows[kMaxDenseRows];
     int n_extras, n_dense;
@@ -87,6 +90,16 @@ struct BtArgs {
     size_t off_lo, off_kind, off_tabA, off_extraA, off_denseA, off_Arow, off_rowc, off_tabX, off_stepC;
     int step_ok, step_kb, step_mult;   // step-structured dense matrix: band = min((dist * step_mult) >> 16, step_kb)
     float step_cn;
+    // half history (wave form, HM 1): row r of a song holds frame 2r; its aux slots mcol / xcol0 + k carry the frame maximum and the
+    // extra-column deltas of frame 2r, slots mcol_odd / xcol0_odd + k those of frame 2r - 1.  The back-trace reads the emissions again.
+    int hist_half;
+    int64_t hist_rows;
+    int mcol_odd, xcol0_odd;
+    const void* logE;       // [B,T,S] the tensor vit_forward decoded (f32 or f16)
+    int e_f16;
+    int32_t* counters;      // [B][kBtCounters] per-song event counts of the sparse / half / half-wave kernels (zeroed by vit_backtrace)
+    int pair_ok;            // the plan built tabH (plan.hpp pair_backtrace_plan_ok)
+    size_t off_tabH;
 };
 
 hipError_t launch_dense(const FwdArgs& a, int songs_per_group, bool f16, hipStream_t st);
@@ -99,7 +112,15 @@ constexpr int wave_hist_stride(int npl) { return 64 * npl; }
 hipError_t launch_backtrace(BtArgs a, hipStream_t st);
 // backtrace_sparse.hip: fetches only the span of each history row around the path (banded plans, candidates on one lane)
 bool sparse_backtrace_applies(const BtArgs& a);
-hipError_t launch_backtrace_sparse(const BtArgs& a, hipStream_t st);
+// phases: bit 0 the speculative pass (one wave per (song, chunk)), bit 1 the verify-and-repair pass (one wave per song)
+hipError_t launch_backtrace_sparse(const BtArgs& a, hipStream_t st, int phases = 3);
+// backtrace_half.hip: the same for a half history (wave form, even rows only): odd frames are rebuilt from the row before them
+bool half_backtrace_applies(const BtArgs& a);
+hipError_t launch_backtrace_half(const BtArgs& a, hipStream_t st, int phases = 3);
+// backtrace_pair.hip: the speculative pass with two (song, chunk) streams per wave (band within 14 sources of the target)
+bool pair_backtrace_applies(const BtArgs& a);
+hipError_t launch_backtrace_pair(const BtArgs& a, hipStream_t st);
+int pair_backtrace_chunks(int64_t B, int T);
 int sparse_backtrace_chunks(int64_t B, int T);
 hipError_t launch_voicing_map(const int32_t* states, int64_t n, int32_t n_bins, uint8_t* voiced, int32_t* bins,
                               hipStream_t st);
@@ -117,6 +138,10 @@ int backtrace_tile_rows(int SD);
 constexpr int kBtWarm = 128;       // warm-up frames of a speculative chunk (survivor paths coalesce within tens of frames)
 constexpr int kBtWarmSparse = 64;  // the sparse kernel runs many short chunks: a shorter warm-up (a wrong guess only costs a repair)
 constexpr int kBtMaxChunks = 32;
+// per-song event counters (include/viterbi_hip.h vit_backtrace_counters): tiles fetched, tiles taken from the prefetch, span
+// misses, whole-row evaluations (bound failures), of those: odd rows rebuilt in full, chunks repaired, frames rewritten by repairs
+constexpr int kBtCounters = 16;
+enum { kCtTiles = 0, kCtPrefetched = 1, kCtMisses = 2, kCtFullRows = 3, kCtRebuilt = 4, kCtRepairs = 5, kCtRepairFrames = 6 };
 int backtrace_chunks(int64_t B, int T);
 
 }  // namespace vit

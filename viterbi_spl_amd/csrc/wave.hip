@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "kernels.hpp"
 
@@ -132,20 +133,27 @@ __device__ __forceinline__ void store_row(float* __restrict__ p, const float (&d
 // out of bounds -- and the history row is stored in slot order: row stride 64*NPL floats, state i in column o + i, and
 // M_t = max_i delta_t[i] in column 0, a copy of delta_t of extra column x in column 1 + x (idle slots).  No branch surrounds a memory instruction, so the in-order vmcnt
 // of the emission prefetch is exact.  The back-trace is told the column offset and the column of M (BtArgs::col0, mcol).
-template <int NPL, int D, int NX, int PF, int WPS, typename ET>
+//
+// HM (history mode).  0: every delta row is stored (row t of a song at hist + t * 64*NPL).  1: only the rows of EVEN frames are
+// stored (row t/2); lane 0's idle slots of row t carry, behind M_t and delta_t of the extra columns, the same scalars of the odd
+// frame t-1 -- they are still in scalar registers when row t is stored, so the odd frames cost no store at all.  The back-trace
+// (backtrace_half.hip) rebuilds the 32 delta values of an odd frame that it needs from the stored row before it and the
+// emission row, with the very sums and maxima of this kernel's recursion: 768 instead of 1536 history bytes per frame.
+template <int NPL, int D, int NX, int PF, int WPS, int HM, typename ET>
 __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
     constexpr int H = wave_halo(NPL, D);
     constexpr int NG = 2 * H + 1;              // lane groups of the neighbourhood
     constexpr int NPM = wave_pairs(D);
     constexpr int SDW = 64 * NPL;              // history row stride of this form
     static_assert(NPL <= 8 && NPL % 2 == 0 && NX <= kWaveMaxExtras && NX + 1 <= NPL && PF >= 1, "geometry (source pairs never straddle two lanes)");
+    static_assert(HM != 1 || 2 * (NX + 1) <= NPL, "half history: lane 0 carries the scalars of two frames");
     const int S = a.S, T = a.T;
     const int lane = threadIdx.x & 63;
     const int song = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (song >= a.B) return;                   // whole waves only; there is no barrier in this kernel
     const int Tb = song_length_of(a.lengths, song, T);
     const ET* __restrict__ E = reinterpret_cast<const ET*>(a.logE) + (size_t)song * T * S;
-    float* __restrict__ hist = a.hist + (size_t)song * T * SDW;
+    float* __restrict__ hist = a.hist + (size_t)song * a.hist_rows * SDW;     // hist_rows = T (HM 0) or (T + 1) / 2 (HM 1)
 
     // ---------------- per-lane constants
     const int o = SDW - S;                                 // idle leading slots (>= 1)
@@ -191,14 +199,21 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
     };
     // history row t in slot order; lane 0's leading slots (always idle: o > NX is checked by the plan) carry M_t and a
     // copy of delta_t of the extra columns, so that the sparse back-trace finds its per-row scalars in ONE cache line
-    auto store_hist = [&](const int t, const float (&d)[NPL], const float M, const float (&xd)[NX > 0 ? NX : 1]) {
+    // (HM 1: row t/2 of an even frame t; Mp / xp = the scalars of frame t-1, slots 1+NX .. 1+2*NX)
+    auto store_hist = [&](const int t, const float (&d)[NPL], const float M, const float (&xd)[NX > 0 ? NX : 1], const float Mp,
+                          const float (&xp)[NX > 0 ? NX : 1]) {
         float v[NPL];
 #pragma unroll
         for (int k = 0; k < NPL; ++k) v[k] = d[k];
         v[0] = lane == 0 ? M : v[0];
 #pragma unroll
         for (int x = 0; x < NX; ++x) v[1 + x] = lane == 0 ? xd[x] : v[1 + x];
-        store_row<NPL>(hist + (size_t)t * SDW + NPL * lane, v);
+        if (HM == 1) {
+            v[1 + NX] = lane == 0 ? Mp : v[1 + NX];
+#pragma unroll
+            for (int x = 0; x < NX; ++x) v[2 + NX + x] = lane == 0 ? xp[x] : v[2 + NX + x];
+        }
+        store_row<NPL>(hist + (size_t)(HM == 1 ? t >> 1 : t) * SDW + NPL * lane, v);
     };
     // delta of the extra columns, wave-uniform
     auto extra_deltas = [&](const float (&d)[NPL], float (&xd)[NX > 0 ? NX : 1]) {
@@ -230,7 +245,7 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
     float M = frame_max(d);
     float xd[NX > 0 ? NX : 1] = {};
     extra_deltas(d, xd);
-    store_hist(0, d, M, xd);
+    store_hist(0, d, M, xd, M, xd);
 
     float er[PF][NPL];
 #pragma unroll
@@ -240,7 +255,7 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
 #pragma unroll
         for (int m = 0; m < NPM; ++m) asm volatile("" ::"v"(aw[k][m]));
 
-    auto frame = [&](const int t, float (&e)[NPL]) {
+    auto frame = [&](const int t, float (&e)[NPL], auto stored) {
         // ---- neighbourhood: group g holds delta of lane l - H + g
         float nb[NG][NPL];
 #pragma unroll
@@ -287,19 +302,32 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
             for (int x = 0; x < NX; ++x) m = fmaxf(m, xd[x] + xa[x][k]);
             d[k] = m + e[k];
         }
+        const float Mp = M;                // the previous frame's scalars (wave-uniform: scalar registers)
+        float xp[NX > 0 ? NX : 1];
+#pragma unroll
+        for (int x = 0; x < (NX > 0 ? NX : 1); ++x) xp[x] = xd[x];
         M = frame_max(d);
         extra_deltas(d, xd);               // for the next frame's candidates, and for the history row
-        store_hist(t, d, M, xd);
-        load_row(t + PF < Tb ? t + PF : Tb - 1, e);
+        if (decltype(stored)::value && HM != 2 && HM != 4) store_hist(t, d, M, xd, Mp, xp);
+        if (HM < 3) load_row(t + PF < Tb ? t + PF : Tb - 1, e);     // (HM 2 / 3 / 4: timing builds only -- no stores / no loads / neither)
     };
+    // The loop body is a whole number of frame pairs when only even frames are stored: t is odd at its top, frame t + q is
+    // even for odd q, and "store or not" is a compile-time property of each unrolled frame (no branch around a store).
+    constexpr int UN = (HM == 1 && (PF & 1)) ? 2 * PF : PF;
     int t = 1;
-    for (; t + PF - 1 < Tb; t += PF) {
+    for (; t + UN - 1 < Tb; t += UN) {
 #pragma unroll
-        for (int q = 0; q < PF; ++q) frame(t + q, er[q]);
+        for (int q = 0; q < UN; ++q) {
+            if (HM != 1 || (q & 1)) frame(t + q, er[q % PF], std::true_type{});
+            else frame(t + q, er[q % PF], std::false_type{});
+        }
     }
 #pragma unroll
-    for (int q = 0; q < PF - 1; ++q)
-        if (t + q < Tb) frame(t + q, er[q]);
+    for (int q = 0; q < UN - 1; ++q)
+        if (t + q < Tb) {
+            if (HM != 1 || (q & 1)) frame(t + q, er[q % PF], std::true_type{});
+            else frame(t + q, er[q % PF], std::false_type{});
+        }
 
     // ---------------- terminal state: lowest-index argmax of delta_{Tb-1}
     {
@@ -334,16 +362,34 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
 template <int NPL, int D, int NX, typename ET>
 static hipError_t launch_wave_x(const FwdArgs& a, hipStream_t st) {
     const int grid = (int)((a.B + 3) / 4);
-    // Emission rows in flight: four in the one-wave-per-SIMD form (up to 1024 songs: the 512-register budget is free
-    // there), three in the two-waves-per-SIMD form.  Measured at S = 361 fp32 (gpurun_out/wave_pf.log): B = 1024
-    // PF 2 / 3 / 4 / 6 / 8 -> 24.6 / 21.4 / 19.9 / 21.5 / 33.8 ms (6 and 8 push the weights into AGPRs / scratch);
-    // B = 2048 PF 2 / 3 -> 38.9 / 37.4 ms.  Non-temporal loads / stores: no effect.
-    // (a second extra column costs six more weight registers and a prefetch row)
+    // Two instantiations: 512 registers (one wave per SIMD, PF1 emission rows in flight) and 256 registers (two waves per
+    // SIMD, PF2 rows).  Round 2 took the first one up to 1024 songs (full history, B = 1024: PF 2 / 3 / 4 / 6 / 8 -> 24.6 /
+    // 21.4 / 19.9 / 21.5 / 33.8 ms).  With the half history the kernel no longer waits for memory and the 256-register
+    // code is the faster one even with a single wave on each SIMD (B = 1024, gpurun_out/r3a/wave_ablate.log: 512-register
+    // form full / half history 19.9 / 21.3 ms, 256-register form 19.7 / 16.5 ms; without any load or store 16.0 ms), so it
+    // runs at every batch size unless a second extra column pushes it into scratch.
     constexpr int PF1 = NX == 2 ? 3 : 4, PF2 = NX == 2 ? 2 : 3;
-    if (a.B <= 1024 && !(a.wave_flags & 1))
-        hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF1, 1, ET>), dim3(grid), dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, ET>), dim3(grid), dim3(256), 0, st, a);
+    const bool one = a.B <= 1024 && !(a.wave_flags & 1) && ((a.wave_flags & 2) || NX == 2);
+#ifdef VIT_TIMING_HOOKS
+    // result-breaking ablations (make TIMING=1 only): bits 0 / 1 of the timing mask drop the history stores / the emission loads
+    if (a.debug & 3) {
+        const int hm = (a.debug & 3) + 1;
+        if (hm == 2) { if (one) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF1, 1, 2, ET>), dim3(grid), dim3(256), 0, st, a);
+                       else hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 2, ET>), dim3(grid), dim3(256), 0, st, a); }
+        else if (hm == 3) { if (one) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF1, 1, 3, ET>), dim3(grid), dim3(256), 0, st, a);
+                            else hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 3, ET>), dim3(grid), dim3(256), 0, st, a); }
+        else { if (one) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF1, 1, 4, ET>), dim3(grid), dim3(256), 0, st, a);
+               else hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 4, ET>), dim3(grid), dim3(256), 0, st, a); }
+        return hipGetLastError();
+    }
+#endif
+    if (a.hist_half) {
+        if (one) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF1, 1, 1, ET>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 1, ET>), dim3(grid), dim3(256), 0, st, a);
+    } else {
+        if (one) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF1, 1, 0, ET>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 0, ET>), dim3(grid), dim3(256), 0, st, a);
+    }
     return hipGetLastError();
 }
 

@@ -90,13 +90,22 @@ class ViterbiDecoder:
         _lib.check(_lib.load().vit_plan_set_option(self._plan, key.encode(), int(value)), f"vit_plan_set_option({key})")
 
     # ------------------------------------------------------------------ workspace
-    def workspace_bytes(self, B: int, T: int) -> int:
-        return int(_lib.load().vit_workspace_bytes(self._plan, B, T))
+    def workspace_bytes(self, B: int, T: int, algo: Optional[str] = None) -> int:
+        """Bytes of workspace a [B,T,S] decode needs: for one `algo` (``vit_workspace_bytes_for`` -- the wave form keeps
+        half a history), or enough for any of them (``vit_workspace_bytes``) when `algo` is None."""
+        lib = _lib.load()
+        if algo is None:
+            return int(lib.vit_workspace_bytes(self._plan, B, T))
+        need = int(lib.vit_workspace_bytes_for(self._plan, B, T, _lib.ALGO[algo]))
+        if need == 0 and B > 0:
+            raise _lib.ViterbiHipError(f"algo {algo!r} is not available for this plan")
+        return need
 
-    def _workspace(self, B: int, T: int, slot: int = 0) -> Tuple[int, int]:
+    def _workspace(self, B: int, T: int, slot: int = 0, algo: Optional[str] = None) -> Tuple[int, int]:
         """Workspace `slot` (callers that overlap the back-trace of one batch with the forward pass of the next on
-        two streams give each batch in flight its own slot; slot 0 is the default)."""
-        need = self.workspace_bytes(B, T)
+        two streams give each batch in flight its own slot; slot 0 is the default).  A buffer that is already large
+        enough is kept, so alternating algos on one decoder settle on the largest need."""
+        need = self.workspace_bytes(B, T, algo)
         ws = self._ws if slot == 0 else self._ws_slots.get(slot)
         if ws is None or ws.numel() < need + 256:
             ws = None
@@ -109,7 +118,7 @@ class ViterbiDecoder:
                 self._ws = ws
             else:
                 self._ws_slots[slot] = ws
-        return (ws.data_ptr() + 255) & ~255, need
+        return (ws.data_ptr() + 255) & ~255, ws.numel() - 256
 
     # ------------------------------------------------------------------ checks
     def _check_emissions(self, logE: torch.Tensor) -> Tuple[torch.Tensor, bool, int]:
@@ -147,7 +156,7 @@ class ViterbiDecoder:
         if lengths is not None:
             if lengths.dtype != torch.int64 or tuple(lengths.shape) != (B,) or lengths.device != self.device:
                 raise ValueError("lengths must be an int64 [B] tensor on the decoder's device")
-        ws_ptr, ws_bytes = self._workspace(B, T, slot)
+        ws_ptr, ws_bytes = self._workspace(B, T, slot, algo)
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
             len_ptr = lengths.data_ptr() if lengths is not None else None
@@ -163,6 +172,23 @@ class ViterbiDecoder:
             else:
                 raise ValueError(phase)
         _lib.check(rc, f"vit_{phase if phase != 'both' else 'decode'}")
+
+    COUNTERS = ("tiles_fetched", "tiles_prefetched", "span_misses", "whole_row_evaluations", "odd_rows_rebuilt",
+                "chunks_repaired", "frames_repaired")
+
+    def backtrace_counters(self, B: int, T: int, slot: int = 0) -> dict:
+        """Event counts of the last back-trace that ran on workspace `slot` (``vit_backtrace_counters``), summed over the songs.
+        Synchronises the device."""
+        ws = self._ws if slot == 0 else self._ws_slots.get(slot)
+        if ws is None:
+            raise _lib.ViterbiHipError("no workspace in this slot")
+        base = (ws.data_ptr() + 255) & ~255
+        off, n = ctypes.c_size_t(), ctypes.c_int32()
+        _lib.check(_lib.load().vit_backtrace_counters(self._plan, B, T, base, ctypes.byref(off), ctypes.byref(n)), "vit_backtrace_counters")
+        torch.cuda.synchronize(self.device)
+        start = base - ws.data_ptr() + off.value
+        ct = ws[start:start + B * n.value * 4].view(torch.int32).view(B, n.value).sum(dim=0).cpu().tolist()
+        return {k: int(ct[i]) for i, k in enumerate(self.COUNTERS)}
 
     def decode(self, emission_logits: torch.Tensor, lengths: Optional[torch.Tensor] = None, algo: str = "auto",
                out_dtype: torch.dtype = torch.int64) -> Tuple[torch.Tensor, torch.Tensor]:
