@@ -14,7 +14,9 @@ behind its back-trace.  The region ends with a device synchronisation and the co
 steps are complete inside it.  `--serial` runs forward, back-trace and gather of a step back to back on one stream.
 
 Rank 0 prints ONE JSON line (always the last line of stdout).  At N = 1 it also carries, measured in the same process:
-  "sweep"    B = 256 / 512 / 1024 / 2048 at S=361 fp32 (the saturation regime; songs repeat with period 32),
+  "sweep"    B = 256 / 512 / 1024 / 2048 at S=361 fp32 (the saturation regime; songs repeat with period 32): serial and
+             overlapped schedules, the wave form with its half and its full delta history, dense emissions, a ragged batch,
+             and the back-trace's data-dependent event counts per 1000 frames,
   "configs4" [256, 30000, 722] fp16 emissions (BASELINE configs[4]): jdc band (d_max 40) and the Durrieu matrix,
   "cpu_baseline" the oracle (NumPy restatement of the reference's loop, one thread) on a bounded sample of the same
              songs -- which doubles as a parity check of the GPU result -- and the C restatement on all cores.
@@ -74,6 +76,16 @@ def make_params(transition, S, dmax):
     return synth.dense_random_log_transition(S, seed=3), synth.dense_random_log_transition(S, seed=4)[0].copy()
 
 
+def limited_by(kernel, B):
+    """What actually binds the forward kernel (the roofline fraction is quoted against HBM whatever this says)."""
+    if kernel == "wave_forward_kernel":
+        return "vector-instruction issue (one song per wavefront: 253 VALU instructions per frame; HBM traffic next)"
+    if kernel.startswith("banded"):
+        return ("latency: one barrier-synchronised frame per ~810 cycles of a song's workgroup (dependent chain barrier -> LDS reads -> "
+                "VALU -> LDS writes -> barrier)" + ("; 128 songs occupy 128 of the 256 CUs" if B <= 128 else ""))
+    return "vector / LDS instruction issue"
+
+
 def forward_kernel_name(dec, algo, B, S):
     """Name of the forward kernel the library launches for (plan, algo, batch): same rules as capi.hip / kernels.hip."""
     info = dec.info
@@ -91,21 +103,21 @@ def forward_kernel_name(dec, algo, B, S):
     return "dense_forward_kernel"
 
 
-def time_serial(dec, E, algo, steps, warmup=1):
+def time_serial(dec, E, algo, steps, warmup=1, lengths=None):
     """forward + back-trace of one batch back to back on the current stream; HIP events around each half."""
     B, T, _ = E.shape
     st = torch.empty((B, T), dtype=torch.int32, device=E.device)
     ll = torch.empty((B,), dtype=torch.float32, device=E.device)
     for _ in range(warmup):
-        dec.decode_into(E, st, ll, algo=algo)
+        dec.decode_into(E, st, ll, lengths, algo=algo)
     torch.cuda.synchronize()
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
     t0 = time.perf_counter()
     for i in range(steps):
         ev[i][0].record()
-        dec.decode_into(E, st, ll, algo=algo, phase="forward")
+        dec.decode_into(E, st, ll, lengths, algo=algo, phase="forward")
         ev[i][1].record()
-        dec.decode_into(E, st, ll, algo=algo, phase="backtrace")
+        dec.decode_into(E, st, ll, lengths, algo=algo, phase="backtrace")
         ev[i][2].record()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
@@ -130,7 +142,7 @@ def valu_ceiling(dec, S, frames, fwd_ms):
             "achieved_Mframes_per_s": frames / (fwd_ms * 1e-3) / 1e6, "frac": frames / (fwd_ms * 1e-3) / peak}
 
 
-def time_overlapped(dec, E, algo, steps, warmup=1):
+def time_overlapped(dec, E, algo, steps, warmup=1, lengths=None):
     """The headline's schedule on any batch: the back-trace of step i on a second stream under the forward pass of step i+1
     (two workspace slots, two path buffers); wall time per step over `steps` complete steps."""
     B, T, _ = E.shape
@@ -138,8 +150,8 @@ def time_overlapped(dec, E, algo, steps, warmup=1):
     st = [torch.empty((B, T), dtype=torch.int32, device=dev) for _ in range(2)]
     ll = [torch.empty((B,), dtype=torch.float32, device=dev) for _ in range(2)]
     for k in range(2):
-        dec._workspace(B, T, k)
-    s_fwd, s_bt = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        dec._workspace(B, T, k, algo)
+    s_fwd, s_bt = torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev)   # forward workgroups are dispatched first
     bt_done = [None, None]
 
     def run(n):
@@ -148,12 +160,12 @@ def time_overlapped(dec, E, algo, steps, warmup=1):
             with torch.cuda.stream(s_fwd):
                 if bt_done[k] is not None:
                     s_fwd.wait_event(bt_done[k])
-                dec.decode_into(E, st[k], ll[k], algo=algo, phase="forward", slot=k)
+                dec.decode_into(E, st[k], ll[k], lengths, algo=algo, phase="forward", slot=k)
                 fwd_done = torch.cuda.Event()
                 fwd_done.record()
             with torch.cuda.stream(s_bt):
                 s_bt.wait_event(fwd_done)
-                dec.decode_into(E, st[k], ll[k], algo=algo, phase="backtrace", slot=k)
+                dec.decode_into(E, st[k], ll[k], lengths, algo=algo, phase="backtrace", slot=k)
                 bt_done[k] = torch.cuda.Event()
                 bt_done[k].record()
         torch.cuda.synchronize()
@@ -182,7 +194,7 @@ def cpu_baseline(logA_T, log_pi, E, gpu_states, gpu_loglik, seconds):
         done += 1
     out = {"value": frames / t_used / 1e6, "unit": "Mframes/s", "cores": 1, "kind": "port",
            "sample": f"first {done} of the batch's songs, T={T}, NumPy float32 loop (oracle/viterbi_oracle.py::decode_numpy)",
-           "bit_exact_vs_gpu": exact, "numpy": np.__version__}
+           "bit_exact_vs_gpu": exact, "numpy": np.__version__, "host": host_info()}
     nthr = min(vo.num_threads(), 16)
     nb = min(E.shape[0], nthr)
     e = E[:nb].float().cpu().numpy()
@@ -194,6 +206,24 @@ def cpu_baseline(logA_T, log_pi, E, gpu_states, gpu_loglik, seconds):
              "sample": f"{nb} songs, T={T}, scalar C restatement, one song per thread (oracle/viterbi_oracle.c)",
              "bit_exact_vs_gpu": exact_c}
     return out, out_c
+
+
+def host_info():
+    """nproc and CPU model of the box the CPU baseline runs on (the reference's own benchmark,
+    dcnet/tf_viterbi_decoding.py:266-282, is a host-CPU number)."""
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count()
+    return {"nproc": os.cpu_count(), "usable_cores": usable, "cpu_model": model}
 
 
 def measure_traffic(B, T, algo, options):
@@ -255,36 +285,93 @@ def oracle_spot_check(logA_T, log_pi, E, states, loglik, songs):
     return bool(np.array_equal(states[songs].cpu().numpy(), rs)) and bool(np.array_equal(loglik[songs].cpu().numpy(), rl))
 
 
+def per_1000_frames(dec, B, T, frames=None, slot=0):
+    ct = dec.backtrace_counters(B, T, slot)
+    n = float(frames if frames is not None else B * T)
+    return {k: round(v * 1000.0 / n, 3) for k, v in ct.items()}
+
+
+def sweep_row(dec, logA_T, log_pi, E, algo, steps, lengths=None, overlapped=True, options=None):
+    """One row of the sweep: forward + back-trace of `E` back to back on one stream (HIP events around each half, `steps`
+    timed steps) and, where two workspace slots fit, the two-stream schedule; fractions of the HBM roofline on ALGORITHMIC
+    bytes; the back-trace's event counts; an oracle spot check of three songs."""
+    B, T, S = E.shape
+    esz = E.element_size()
+    dec.set_option("reset", 0)
+    for k, v in (options or {}).items():
+        dec.set_option(k, v)
+    frames = int(lengths.sum().item()) if lengths is not None else B * T
+    r, st, ll = time_serial(dec, E, algo, steps=steps, lengths=lengths)
+    ser_ms = r["forward_ms"] + r["backtrace_ms"]
+    r.update({"songs": B, "frames_decoded": frames, "Mframes_per_s": frames / ser_ms / 1e3,
+              "forward_kernel": forward_kernel_name(dec, algo, B, S),
+              "history": dec.history_mode(B, T, algo),
+              "workspace_GB": dec.workspace_bytes(B, T, algo) / 1e9,
+              "forward_hbm_frac": frames * (S * esz + S * 2) / (r["forward_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+              "whole_path_hbm_frac": frames * (S * esz + S * 2 + 6) / (ser_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+              "backtrace_events_per_1000_frames": per_1000_frames(dec, B, T, frames)})
+    vc = valu_ceiling(dec, S, frames, r["forward_ms"])
+    if vc:
+        r["forward_valu_frac"] = vc["frac"]
+    sub = [0, min(B, 32) // 2, min(B, 32) - 1]
+    rs, rl = __import__("oracle.viterbi_oracle", fromlist=["x"]).decode_c(
+        logA_T, log_pi, E[sub].float().cpu().numpy(), lengths=None if lengths is None else lengths[sub].cpu().numpy())
+    r["bit_exact_vs_oracle_sample"] = bool(np.array_equal(st[sub].cpu().numpy(), rs)) and bool(np.array_equal(ll[sub].cpu().numpy(), rl))
+    if overlapped:
+        try:
+            wall, st2, ll2 = time_overlapped(dec, E, algo, steps=steps, lengths=lengths)
+            r.update({"overlapped_ms_per_step": wall, "Mframes_per_s_overlapped": frames / wall / 1e3,
+                      "overlapped_equals_serial": bool(torch.equal(st2, st) and torch.equal(ll2, ll))})
+            del st2, ll2
+        except torch.OutOfMemoryError:
+            r["overlapped_ms_per_step"] = None       # two workspace slots do not fit beside the emissions
+        # the schedule a caller should use for this batch: never one that is slower than its serial twin
+        ov = r.get("overlapped_ms_per_step")
+        r["best_schedule"] = "two streams" if ov is not None and ov < ser_ms else "one stream"
+        r["Mframes_per_s_best"] = frames / min(ser_ms, ov if ov is not None else ser_ms) / 1e3
+    del st, ll
+    dec._ws = None
+    dec._ws_slots = {}
+    dec.set_option("reset", 0)
+    torch.cuda.empty_cache()
+    return r
+
+
 def extra_blocks(dev, args):
     """The saturation sweep and the high-resolution configuration, measured in this process after the headline."""
     out = {}
     T = args.frames
-    # ---- sweep: S=361 fp32, tonet matrix, larger batches (same kernels the library picks for those sizes)
+    NS = 10                     # timed steps per row
+    # ---- sweep: S=361 fp32, tonet matrix, larger batches (the kernels the library picks for those sizes, and the alternatives)
     logA_T, log_pi = make_params("tonet", 361, 14)
     dec = ViterbiDecoder(logA_T, log_pi, dev)
     sweep = {}
     for B in (256, 512, 1024, 2048):
         E = tiled_emissions(synth.emissions_peaks, B, T, 361, 1234, dev, torch.float32)
-        r, st, ll = time_serial(dec, E, "banded", steps=3)
-        fb = B * T * (361 * 4 + 361 * 2)
-        r.update({"songs": B, "Mframes_per_s": B * T / (r["forward_ms"] + r["backtrace_ms"]) / 1e3,
-                  "forward_kernel": forward_kernel_name(dec, "banded", B, 361),
-                  "forward_hbm_frac": fb / (r["forward_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                  "forward_valu_frac": valu_ceiling(dec, 361, B * T, r["forward_ms"])["frac"],
-                  "whole_path_hbm_frac": B * T * 2172 / ((r["forward_ms"] + r["backtrace_ms"]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                  "bit_exact_vs_oracle_sample": oracle_spot_check(logA_T, log_pi, E, st, ll, [0, 17, 31])})
-        if B <= 1024:     # (two workspace slots of 2048 songs do not fit beside the emissions)
-            wall, st2, ll2 = time_overlapped(dec, E, "banded", steps=4)
-            r.update({"overlapped_ms_per_step": wall, "Mframes_per_s_overlapped": B * T / wall / 1e3,
-                      "overlapped_equals_serial": bool(torch.equal(st2, st) and torch.equal(ll2, ll))})
-            del st2, ll2
-        sweep[f"B{B}"] = r
-        del E, st, ll
-        dec._ws = None
+        sweep[f"B{B}"] = sweep_row(dec, logA_T, log_pi, E, "banded", NS)
+        if B >= 1024:           # the wave form with the delta rows of even frames only (vit_plan_set_option "wave_history" = 2)
+            sweep[f"B{B}_half_history"] = sweep_row(dec, logA_T, log_pi, E, "banded", NS, options={"wave_history": 2})
+        del E
         torch.cuda.empty_cache()
-    out["sweep"] = {"workload": f"T={T}, S=361, fp32 log-emissions (peaks), tonet transition; songs repeat with period 32; "
-                                "forward + back-trace back to back on one stream, 3 steps (Mframes_per_s); "
-                                "*_overlapped: the headline's two-stream schedule, 4 steps", **sweep}
+    # data-dependent costs: dense i.i.d. emissions (SURVEY 8d's second distribution) and a ragged batch
+    for B in (128, 1024):
+        E = tiled_emissions(synth.emissions_dense, B, T, 361, 1234, dev, torch.float32)
+        sweep[f"B{B}_dense_emissions"] = sweep_row(dec, logA_T, log_pi, E, "banded", NS, overlapped=False)
+        del E
+        torch.cuda.empty_cache()
+    for B in (128, 1024):
+        E = tiled_emissions(synth.emissions_peaks, B, T, 361, 1234, dev, torch.float32)
+        g = torch.Generator().manual_seed(7)
+        lengths = torch.randint(T // 4, T + 1, (B,), generator=g, dtype=torch.int64).to(dev)
+        sweep[f"B{B}_ragged"] = sweep_row(dec, logA_T, log_pi, E, "banded", NS, lengths=lengths, overlapped=False)
+        sweep[f"B{B}_ragged"]["lengths"] = f"uniform in [{T // 4}, {T}], mean {float(lengths.float().mean()):.0f}; block order (not sorted)"
+        sweep[f"B{B}_ragged"]["forward_ms_if_all_full_length"] = sweep[f"B{B}"]["forward_ms"] if f"B{B}" in sweep else None
+        del E
+        torch.cuda.empty_cache()
+    out["sweep"] = {"workload": f"T={T}, S=361, fp32 log-emissions (peaks unless the row says dense), tonet transition; songs repeat with period 32; "
+                                f"{NS} timed steps per row: forward + back-trace back to back on one stream (forward_ms, backtrace_ms, Mframes_per_s) and "
+                                "the two-stream schedule of the headline (overlapped_*); *_hbm_frac on algorithmic bytes (SURVEY 8d); "
+                                "ragged rows count the frames actually decoded", **sweep}
     del dec
     # ---- configs[4]: S=722 (721 bins + unvoiced), fp16 emissions, 256 songs
     c4 = {}
@@ -292,17 +379,19 @@ def extra_blocks(dev, args):
         A, pi = make_params(tr, 722, dmax or 14)
         dec = ViterbiDecoder(A, pi, dev)
         E = tiled_emissions(synth.emissions_peaks, 256, T, 722, 1234, dev, torch.float16)
-        r, st, ll = time_serial(dec, E, "auto", steps=2)
-        fb = 256 * T * (722 * 2 + 722 * 2)
-        r.update({"Mframes_per_s": 256 * T / (r["forward_ms"] + r["backtrace_ms"]) / 1e3,
-                  "forward_kernel": forward_kernel_name(dec, "auto", 256, 722),
-                  "forward_hbm_frac": fb / (r["forward_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                  "bit_exact_vs_oracle_sample": oracle_spot_check(A, pi, E, st, ll, [0, 31])})
+        r = sweep_row(dec, A, pi, E, "auto", NS, overlapped=False)
+        if dec.info["banded_ok"]:
+            r["valu_ceiling"] = valu_ceiling(dec, 722, 256 * T, r["forward_ms"])
+        else:   # the step-structured kernel: 2 x 9 band windows of 20 sources + the far maximum per target
+            cand = 2 * 9 * 20 + 2
+            peak = VALU_LANE_RATE / (722 * cand)
+            r["valu_ceiling"] = {"candidates_per_state": cand, "lane_instructions_per_frame": 722 * cand, "peak_Mframes_per_s": peak / 1e6,
+                                 "achieved_Mframes_per_s": 256 * T / (r["forward_ms"] * 1e-3) / 1e6, "frac": 256 * T / (r["forward_ms"] * 1e-3) / peak}
         c4[name] = r
-        del E, st, ll, dec
+        del E, dec
         torch.cuda.empty_cache()
     out["configs4"] = {"workload": f"[256, {T}, 722] fp16 log-emissions (peaks), songs repeat with period 32 (BASELINE configs[4]); "
-                                   "2 steps, one stream", **c4}
+                                   f"{NS} timed steps, one stream", **c4}
     return out
 
 
@@ -335,25 +424,16 @@ def main():
     n_total = B * world
     NSLOT = 1 if (args.serial and not use_dist) else 2     # batches in flight
     for k in range(NSLOT):
-        dec._workspace(B, T, k)                              # allocate before anything is timed
+        dec._workspace(B, T, k, algo)                        # allocate before anything is timed
     states_k = [torch.empty((B, T), dtype=torch.int32, device=dev) for _ in range(NSLOT)]
     loglik_k = [torch.empty((B,), dtype=torch.float32, device=dev) for _ in range(NSLOT)]
-    if use_dist and rank == 0:
-        out_k = [(torch.empty((world, B, T), dtype=torch.int32, device=dev), torch.empty((world, B), dtype=torch.float32, device=dev))
-                 for _ in range(NSLOT)]
-    else:
-        out_k = [(None, None)] * NSLOT
-    pending = [None] * NSLOT        # gather handles per slot
+    pipe = sharded.GatherPipeline(B, T, dev, n_slots=NSLOT) if use_dist else None    # gather buffers + handles per slot (rank 0 receives)
     bt_done = [None] * NSLOT        # event: back-trace of the batch in this slot finished
     s_fwd = torch.cuda.Stream(device=dev, priority=-1)        # the forward pass is the critical path: its workgroups go first
     s_bt = torch.cuda.Stream(device=dev) if not args.serial else s_fwd
 
     def step(i, ev=None):
-        k = i % NSLOT
-        if pending[k] is not None:                     # gather(i - NSLOT) still reads states_k[k]
-            for w in pending[k]:
-                w.wait()
-            pending[k] = None
+        k = pipe.acquire(i) if pipe is not None else i % NSLOT     # (waits for gather(i - NSLOT), which still reads states_k[k])
         with torch.cuda.stream(s_fwd):
             if bt_done[k] is not None and s_bt is not s_fwd:
                 s_fwd.wait_event(bt_done[k])           # back-trace(i - NSLOT) still reads workspace slot k
@@ -374,19 +454,14 @@ def main():
                 ev[3].record()
             bt_done[k] = torch.cuda.Event()
             bt_done[k].record()
-            if use_dist:                               # ordered behind the back-trace (current stream), runs on the communicator's stream
-                pending[k] = sharded.gather_paths_async(states_k[k], loglik_k[k], out_k[k][0], out_k[k][1], dst=0)
+            if pipe is not None:                       # ordered behind the back-trace (current stream), runs on the communicator's stream
+                pipe.submit(k, states_k[k], loglik_k[k])
                 if args.serial:
-                    for w in pending[k]:
-                        w.wait()
-                    pending[k] = None
+                    pipe.wait(k)
 
     def drain():
-        for k in range(NSLOT):
-            if pending[k] is not None:
-                for w in pending[k]:
-                    w.wait()
-                pending[k] = None
+        if pipe is not None:
+            pipe.drain()
         torch.cuda.synchronize()
 
     def timed(n, with_events):
@@ -407,6 +482,12 @@ def main():
             dt_ = float(tmax.item())
         return dt_, evs
 
+    ranks_info = None
+    if use_dist:                       # who is in the job, as the communicator sees it (outside the timed region)
+        mine = {"rank": rank, "local_rank": local_rank, "device": f"cuda:{local_rank}", "name": torch.cuda.get_device_name(dev),
+                "songs": [rank * B, rank * B + B]}
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, mine)
     for k in range(NSLOT):             # prime every slot once (code objects, first touch of the workspaces) whatever --warmup says
         step(k)
     drain()
@@ -448,7 +529,7 @@ def main():
             "metric": "Viterbi Mframes/s at S=361 T=30k; achieved HBM GB/s vs peak",
             "value": value, "unit": "Mframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "emission_storage": "f16" if args.f16 else "f32", "data": "synthetic",
             "config": {"workload": workload, "songs_per_gpu": B, "frames": T, "states": S, "emissions": args.emissions,
                        "emission_storage": "f16" if args.f16 else "f32",
                        "transition": args.transition, "band_half_width": args.dmax if args.transition == "tonet" else None,
@@ -456,7 +537,9 @@ def main():
             "schedule": ("one stream: forward, back-trace" + (", gather" if use_dist else "") + " of a step back to back") if args.serial else
                         ("two streams: back-trace of step i overlaps the forward pass of step i+1; two workspace slots" +
                          ("; non-blocking gather on the communicator's stream" if use_dist else "")),
-            "roofline": {"bound": "hbm", "kernel": fwd_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "distributed": None if not use_dist else {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": ranks_info,
+                                                      "gathers_launched_on_rank0": pipe.launched, "gather": "non-blocking dist.gather of states [B,T] int32 + loglik [B] to rank 0 per step"},
+            "roofline": {"bound": "hbm", "limited_by": limited_by(fwd_kernel, B), "kernel": fwd_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": fwd_bytes, "avg_launch_ms": fwd_ms, "bytes_per_frame": bpf,
                          "note": "algorithmic bytes per SURVEY 8d (emission row in + uint16 back-pointer row out); the kernels "

@@ -104,16 +104,17 @@ int vit_plan_query(const vit_plan *plan, vit_plan_info *info);
  * scripts can reach each kernel form (the library reads NO environment variables).  Keys:
  *   "forward_form"     banded plans: 0 by batch size | 1 one target per lane | 2 two targets per lane | 3 scan form |
  *                      4 wave form | 5 never the wave form
- *   "backtrace_form"   0 auto | 1 generic kernel | 2 whole-row kernels (no sparse fetch) | 3 sparse fetch, one (song, chunk)
- *                      stream per wavefront (auto walks two per wavefront where the band is within 14 sources of the target)
+ *   "backtrace_form"   0 auto | 1 generic kernel | 2 whole-row kernels (no sparse fetch)
  *   "dense_songs"      songs per workgroup of the dense kernel (0 auto); "dense_one_thread" 1 = one thread per target;
  *                      "dense_form" 0 = matrix-resident dense kernel where it applies (64 < S <= 368), 1 = always stream the matrix
  *   "step_form"        step-structured kernel: 0 four targets per lane, bands split over two waves | 1 one target per lane |
  *                      2 off (plain dense kernel) | 3 four targets per lane, one wave per lane group
  *   "bt_chunks", "bt_warm"   time-parallel back-trace: chunks per song (0 auto), warm-up frames (-1 default)
  *   "win_shift"        LDS window shift 0..3 (-1 from the plan); "wave_min_batch" (0 default), "wave_two" 1
- *   "wave_history"     wave form: 0 = store the delta rows of even frames only where the plan allows it (the back-trace
- *                      rebuilds the odd ones; half the history bytes) | 1 = every row | 2 = half, VIT_EUNSUPPORTED otherwise
+ *   "wave_history"     wave form: 0 / 1 = store every delta row | 2 = store the rows of even frames only (the back-trace rebuilds
+ *                      the 32 values an odd frame needs from the row before it and the emissions): half the workspace and a
+ *                      faster forward pass for a slower back-trace; VIT_EUNSUPPORTED where the plan does not
+ *                      allow it (window 32 wide with an affine start, <= 2 extra columns, S <= 378)
  *   "timing"           ablation / probe mask: accepted only by a -DVIT_TIMING_HOOKS build (VIT_EUNSUPPORTED otherwise;
  *                      those bits change results)
  *   "reset"            back to the defaults
@@ -164,10 +165,10 @@ int vit_backtrace(const vit_plan *plan, int64_t B, int64_t T, const int64_t *len
 
 /* Event counts of the last vit_backtrace() on this workspace (banded plans; all zero for the kernels that do not count):
  * *offset = byte offset, inside the workspace, of an int32 [B][*n_per_song] device array (valid once the back-trace has run
- * on its stream): per song [0] tiles fetched, [1] tiles taken from the prefetch, [2] span misses (the path left the fetched
- * columns), [3] whole-row evaluations (the bound fl(M_t + c_j) could not exclude the row constant), [4] of those: odd rows
- * of a half history rebuilt in full, [5] chunks repaired by the verify pass, [6] frames rewritten by repairs.  The data-
- * dependent part of the back-trace's cost; bench.py reports it per 1000 frames. */
+ * on its stream): per song [0] tiles fetched, [1] span misses (the path left the fetched columns), [2] whole-row evaluations
+ * (the bound fl(M_t + c_j) could not exclude the row constant), [3] of those: odd rows of a half history rebuilt in full,
+ * [4] chunks repaired by the verify pass, [5] frames rewritten by repairs.  The data-dependent part of the back-trace's cost;
+ * bench.py reports it per 1000 frames. */
 int vit_backtrace_counters(const vit_plan *plan, int64_t B, int64_t T, const void *workspace, size_t *offset,
                            int32_t *n_per_song);
 

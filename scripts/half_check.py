@@ -29,7 +29,7 @@ for name in ("tonet361", "msnet321"):
                 E = gen(11, Tm, S, seed=5, device=dev, dtype=torch.float16 if f16 else torch.float32)
                 lens = torch.tensor([Tm, 1, 2, 150, Tm - 1, 3, 64, 65, 66, 4, 5], dtype=torch.int64, device=dev)
                 ref_s, ref_l = vo.decode_c(A, pi, E.float().cpu().numpy(), lengths=lens.cpu().numpy())
-                for algo, hist, btf in (("wave", 2, 0), ("wave", 2, 3), ("wave", 1, 0), ("wave", 1, 3), ("group", 1, 0)):
+                for algo, hist, btf in (("wave", 2, 0), ("wave", 1, 0), ("group", 1, 0)):
                     for chunks, warm in ((0, -1), (7, 0), (32, 1), (1, -1), (5, 33), (2, 7)):
                         dec.set_option("reset", 0)
                         dec.set_option("wave_history", hist)
@@ -60,11 +60,9 @@ for kind in kinds:
         st = torch.empty((B, T), dtype=torch.int32, device=dev)
         ll = torch.empty((B,), dtype=torch.float32, device=dev)
         ref = None
-        for hist, btf, chunks in ((1, 3, 0), (1, 4, 0), (1, 4, max(1, 8192 // B)), (1, 3, max(1, 8192 // B))):
+        for hist in (1, 2):
             dec.set_option("reset", 0)
             dec.set_option("wave_history", hist)
-            dec.set_option("backtrace_form", btf)
-            dec.set_option("bt_chunks", min(chunks, 32))
             dec._ws = None
             torch.cuda.empty_cache()
             dec.decode_into(E, st, ll, algo="wave")      # warm
@@ -86,7 +84,7 @@ for kind in kinds:
             same = "" if ref is None else f"  same paths: {bool(torch.equal(ref, st))}"
             fr = B * T * 2166 / (tf * 1e-3) / 8e12
             wr = B * T * 2172 / ((tf + tb) * 1e-3) / 8e12
-            print(f"{kind} B {B} history {'full' if hist == 1 else 'half'} bt form {btf} chunks {chunks}: fwd {tf:.2f} ms  bt {tb:.2f} ms  -> fwd {B*T/tf/1e3:.0f} Mframes/s ({fr:.3f} of the roofline), "
+            print(f"{kind} B {B} history {'full' if hist == 1 else 'half'} : fwd {tf:.2f} ms  bt {tb:.2f} ms  -> fwd {B*T/tf/1e3:.0f} Mframes/s ({fr:.3f} of the roofline), "
                   f"whole {B*T/(tf+tb)/1e3:.0f} Mframes/s ({wr:.3f}){same}", flush=True)
             ct = dec.backtrace_counters(B, T)
             print("      per 1000 frames:", {k: round(v * 1000.0 / (B * T), 3) for k, v in ct.items()}, flush=True)

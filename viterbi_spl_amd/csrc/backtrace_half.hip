@@ -136,9 +136,9 @@ __global__ void __launch_bounds__(1024) half_backtrace_kernel(BtArgs a) {
     const int c0_max = (SD - kHbND) & ~3;
     const int ce_max = S - kHbNE;
 
-    // Tile I/O in two halves, so that the next tile's loads are in flight while this one is walked (MODE 0; see
-    // backtrace_sparse.hip).  A tile = stored rows r_lo .. r_lo + rows - 1: their delta spans, the scalars of rows r_lo ..
-    // r_lo + rows, the emission spans of the odd frames 2r + 1.
+    // A tile = stored rows r_lo .. r_lo + rows - 1: their delta spans, the scalars of rows r_lo .. r_lo + rows, the emission
+    // spans of the odd frames 2r + 1.  (Fetching the next tile ahead into registers was measured: no gain -- the sixteen waves of a
+    // CU already hide the fetch -- at 25 more registers.)
     struct TileRegs { f32x4 sd[3]; f32x4 sa; float se[kHbR]; };
     auto tile_load = [&](const int r_lo, const int rows, const int c0, const int ce0, TileRegs& tr) {
 #pragma unroll
@@ -171,14 +171,11 @@ __global__ void __launch_bounds__(1024) half_backtrace_kernel(BtArgs a) {
 #pragma unroll
         for (int r = 0; r < kHbR; ++r) te[r * kHbNE + lane] = tr.se[r];
     };
-    constexpr bool kPrefetch = MODE == 0;
-    int n_tiles = 0, n_pref = 0, n_miss = 0, n_full = 0, n_reb = 0, n_rep = 0, n_repf = 0;      // event counts of this wave
+    int n_tiles = 0, n_miss = 0, n_full = 0, n_reb = 0, n_rep = 0, n_repf = 0;      // event counts of this wave
 
     // chase(top, bottom, cur, write): decide the states of frames top .. bottom (descending), starting from state `cur`
     // at frame top+1.
     auto chase = [&](int top, const int bottom, int cur, const bool write) -> int {
-        TileRegs pf;
-        int pf_top = -1, pf_c0 = 0, pf_ce0 = 0;
         while (top >= bottom) {
             cur = __builtin_amdgcn_readfirstlane(cur);
             const int r_hi = top >> 1;
@@ -193,31 +190,11 @@ __global__ void __launch_bounds__(1024) half_backtrace_kernel(BtArgs a) {
             c0 = c0 < 0 ? 0 : (c0 > c0_max ? c0_max : c0);
             int ce0 = lo_c - (kHbNE - W) / 2;
             ce0 = ce0 < 0 ? 0 : (ce0 > ce_max ? ce_max : ce0);
-            bool use_pf = false;
-            if (kPrefetch && pf_top == top) {              // does the first frame of the tile fit the columns in flight?
-                const int s_lo = a.col0 + lo_of(lo_c) - pf_c0, s_hi = a.col0 + lo_of(lo_c + W - 1) + W - pf_c0;
-                use_pf = s_lo >= 0 && s_hi <= kHbND && lo_c >= pf_ce0 && lo_c + W <= pf_ce0 + kHbNE;
-            }
-            if (use_pf) {
-                c0 = pf_c0;
-                ce0 = pf_ce0;
-                tile_store(pf);
-                ++n_pref;
-            } else {
-                ++n_tiles;
+            ++n_tiles;
+            {
                 TileRegs tr;
                 tile_load(r_lo, rows, c0, ce0, tr);
                 tile_store(tr);
-            }
-            pf_top = -1;
-            if (kPrefetch && first - 1 >= bottom) {
-                pf_top = first - 1;
-                pf_c0 = c0;
-                pf_ce0 = ce0;
-                const int nr_hi = pf_top >> 1;
-                int nr_lo = nr_hi - (kHbR - 1);
-                nr_lo = nr_lo < (bottom >> 1) ? (bottom >> 1) : nr_lo;
-                tile_load(nr_lo, nr_hi - nr_lo + 1, c0, ce0, pf);
             }
             int outv = 0;
             const int oldv = (MODE == 1 && lane < nfr) ? states[first + lane] : -1;
@@ -392,7 +369,6 @@ __global__ void __launch_bounds__(1024) half_backtrace_kernel(BtArgs a) {
     if (lane == 0 && a.counters) {
         int32_t* ct = a.counters + (size_t)song * kBtCounters;
         if (n_tiles) atomicAdd(ct + kCtTiles, n_tiles);
-        if (n_pref) atomicAdd(ct + kCtPrefetched, n_pref);
         if (n_miss) atomicAdd(ct + kCtMisses, n_miss);
         if (n_full) atomicAdd(ct + kCtFullRows, n_full);
         if (n_reb) atomicAdd(ct + kCtRebuilt, n_reb);

@@ -64,7 +64,7 @@ __device__ __forceinline__ float sp_wave_max(float x) {   // kernels.hip wave_ma
 // the bound): 1 for windows up to 59 wide, 2 up to 123 (the jdc band on the 722-state grid: W = 96), 3 for W = 128 (imm).  GT: the per-target
 // candidate table is read from the plan image (L2) instead of LDS -- at S = 722, W = 96 it is 310 KB.
 template <int NWT, bool AFF, int MODE, int KC, bool GT>
-__global__ void __launch_bounds__(1024, (GT && KC == 1) ? 8 : 4) sparse_backtrace_kernel(BtArgs a) {
+__global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int EPL = NWT;
     constexpr int kSpNS = sp_span(KC);
@@ -132,71 +132,46 @@ __global__ void __launch_bounds__(1024, (GT && KC == 1) ? 8 : 4) sparse_backtrac
     const int lo_max = S - W;
     const int c0_max = (SD - kSpNS) & ~3;    // (rows are 16-byte aligned; the clamp may leave the last span 16-byte aligned only)
 
-    // Tile I/O in two halves so that the NEXT tile's loads can be in flight while this one is walked (MODE 0): the kernel
-    // waited for HBM once per tile -- ~60 % of a wave's cycles in SQ_WAIT_ANY at B = 1024 (profiles/r02_pmc_B1024_wave_sparse.txt),
-    // most of it the ~2-3 us of this fetch spread over sixteen decisions.  The prefetch keeps the columns of the current tile (the
-    // best guess for a slowly moving path); if the path has left them by the time the tile is due, it is fetched again, centred.
-    auto tile_load = [&](const int first, const int rows, const int c0, f32x4 (&stage)[kSpVec], float (&auxv)[2]) {
-#pragma unroll
-        for (int v = 0; v < kSpVec; ++v) {
-            const int idx = lane + 64 * v;
-            int r = idx / (kSpNS / 4);
-            const int q = idx % (kSpNS / 4);
-            r = r < rows ? r : rows - 1;
-            stage[v] = *reinterpret_cast<const f32x4*>(hist + (size_t)(first + r) * SD + c0 + 4 * q);
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            int r = (lane >> 3) + 8 * h;
-            r = r < rows ? r : rows - 1;
-            auxv[h] = hist[(size_t)(first + r) * SD + aux_col];
-        }
-    };
-    auto tile_store = [&](const f32x4 (&stage)[kSpVec], const float (&auxv)[2]) {
-#pragma unroll
-        for (int v = 0; v < kSpVec; ++v) {
-            const int idx = lane + 64 * v;
-            *reinterpret_cast<f32x4*>(tile + (idx / (kSpNS / 4)) * kSpRS + 4 * (idx % (kSpNS / 4))) = stage[v];
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) tile[((lane >> 3) + 8 * h) * kSpRS + kSpNS + aux_e] = auxv[h];
-    };
-    constexpr bool kPrefetch = MODE == 0;
-    int n_tiles = 0, n_pref = 0, n_miss = 0, n_full = 0, n_rep = 0, n_repf = 0;      // event counts of this wave (scalar registers)
+    int n_tiles = 0, n_miss = 0, n_full = 0, n_rep = 0, n_repf = 0;      // event counts of this wave (vit_backtrace_counters)
 
     // chase(top, bottom, cur, write): decide the states of frames top .. bottom (descending) from the delta rows
     // top .. bottom, starting from state `cur` at frame top+1.
     auto chase = [&](int top, const int bottom, int cur, const bool write) -> int {
-        f32x4 pf_stage[kSpVec];
-        float pf_aux[2];
-        int pf_top = -1, pf_c0 = 0;              // tile in flight: rows pf_top - kSpK + 1 (clipped at bottom) .. pf_top, columns pf_c0 ..
         while (top >= bottom) {
             cur = __builtin_amdgcn_readfirstlane(cur);
             const int first = top - kSpK + 1 > bottom ? top - kSpK + 1 : bottom;
             const int rows = top - first + 1;
-            // ---- the tile: span columns [c0, c0 + NS) of rows first .. top, centred on the window of `cur`
+            // ---- fetch the tile: span columns [c0, c0 + NS) of rows first .. top, centred on the window of `cur`
             int lo_c;
             if (AFF) { lo_c = cur - a.lo_off; lo_c = lo_c < 0 ? 0 : (lo_c > lo_max ? lo_max : lo_c); }
             else lo_c = __builtin_amdgcn_readfirstlane(loL[cur]);
             int c0 = (a.col0 + lo_c - (kSpNS - W) / 4) & ~15;      // 64-byte aligned: the span touches 2.5 lines of 128 B on average instead of 2.9
             c0 = c0 < 0 ? 0 : (c0 > c0_max ? c0_max : c0);
-            if (kPrefetch && pf_top == top && a.col0 + lo_c - pf_c0 >= 0 && a.col0 + lo_c - pf_c0 + W <= kSpNS) {
-                c0 = pf_c0;
-                tile_store(pf_stage, pf_aux);
-                ++n_pref;
-            } else {
-                ++n_tiles;
+            ++n_tiles;
+            {
                 f32x4 stage[kSpVec];
                 float auxv[2];
-                tile_load(first, rows, c0, stage, auxv);
-                tile_store(stage, auxv);
-            }
-            pf_top = -1;
-            if (kPrefetch && first - 1 >= bottom) {
-                pf_top = first - 1;
-                pf_c0 = c0;
-                const int nfirst = pf_top - kSpK + 1 > bottom ? pf_top - kSpK + 1 : bottom;
-                tile_load(nfirst, pf_top - nfirst + 1, c0, pf_stage, pf_aux);
+#pragma unroll
+                for (int v = 0; v < kSpVec; ++v) {
+                    const int idx = lane + 64 * v;
+                    int r = idx / (kSpNS / 4);
+                    const int q = idx % (kSpNS / 4);
+                    r = r < rows ? r : rows - 1;
+                    stage[v] = *reinterpret_cast<const f32x4*>(hist + (size_t)(first + r) * SD + c0 + 4 * q);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    int r = (lane >> 3) + 8 * h;
+                    r = r < rows ? r : rows - 1;
+                    auxv[h] = hist[(size_t)(first + r) * SD + aux_col];
+                }
+#pragma unroll
+                for (int v = 0; v < kSpVec; ++v) {
+                    const int idx = lane + 64 * v;
+                    *reinterpret_cast<f32x4*>(tile + (idx / (kSpNS / 4)) * kSpRS + 4 * (idx % (kSpNS / 4))) = stage[v];
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) tile[((lane >> 3) + 8 * h) * kSpRS + kSpNS + aux_e] = auxv[h];
             }
             int outv = 0;
             const int oldv = (MODE == 1 && lane < rows) ? states[first + lane] : -1;
@@ -348,7 +323,6 @@ __global__ void __launch_bounds__(1024, (GT && KC == 1) ? 8 : 4) sparse_backtrac
     if (lane == 0 && a.counters) {
         int32_t* ct = a.counters + (size_t)song * kBtCounters;
         if (n_tiles) atomicAdd(ct + kCtTiles, n_tiles);
-        if (n_pref) atomicAdd(ct + kCtPrefetched, n_pref);
         if (n_miss) atomicAdd(ct + kCtMisses, n_miss);
         if (n_full) atomicAdd(ct + kCtFullRows, n_full);
         if (n_rep) atomicAdd(ct + kCtRepairs, n_rep);
@@ -391,7 +365,7 @@ static hipError_t launch_sparse_t(const BtArgs& a, hipStream_t st, int phases) {
 
 template <int NWT>
 static hipError_t launch_sparse_a(const BtArgs& a, hipStream_t st, int phases) {
-    const bool gt = !sparse_table_fits(a) || a.bt_form == 4;
+    const bool gt = !sparse_table_fits(a);
     if (sparse_kc(a) == 1) {
         if (gt) return a.lo_affine ? launch_sparse_t<NWT, true, 1, true>(a, st, phases) : launch_sparse_t<NWT, false, 1, true>(a, st, phases);
         return a.lo_affine ? launch_sparse_t<NWT, true, 1, false>(a, st, phases) : launch_sparse_t<NWT, false, 1, false>(a, st, phases);

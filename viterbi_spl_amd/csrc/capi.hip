@@ -18,7 +18,7 @@
 struct Tuning {
     int forward_form = 0;      // banded plans: 0 by batch size | 1 one target per lane | 2 two targets per lane | 3 scan form
                                //               | 4 wave form (one song per wavefront) | 5 never the wave form
-    int backtrace_form = 0;    // 0 auto | 1 generic (lazy) kernel | 2 whole-row kernels | 3 sparse fetch with one stream per wave (no half-wave pass)
+    int backtrace_form = 0;    // 0 auto | 1 generic (lazy) kernel | 2 whole-row kernels
     int dense_songs = 0;       // songs per workgroup of the dense kernel (0 = by batch size)
     int dense_one_thread = 0;  // 1: one thread per target in the dense kernel even where two fit
     int dense_form = 0;        // 0: matrix-resident dense kernel where it applies (64 < S <= 368) | 1: always the streaming kernel
@@ -29,7 +29,7 @@ struct Tuning {
     int wave_min_batch = 0;    // batch size from which banded plans take the wave form (0 = default)
     int wave_two = 0;          // wave kernel: 1 always the 256-register instantiation (the default but for two extra columns) | 2 the 512-register
                                // one up to 1024 songs
-    int wave_history = 0;      // wave form: 0 half history (even rows) where the plan allows it | 1 every row | 2 half, or VIT_EUNSUPPORTED
+    int wave_history = 0;      // wave form: 0 / 1 every delta row | 2 the rows of even frames only (VIT_EUNSUPPORTED where the plan does not allow it)
     int timing = 0;
 };
 
@@ -116,7 +116,7 @@ WsLayout ws_layout(const vit_plan* p, int64_t B, int64_t T) { return ws_layout_h
 // Does the wave form of this plan store a half history (even frames only)?  The back-trace kernel for it
 // (backtrace_half.hip) is asked with the layout the forward kernel would write.
 bool wave_half_applies(const vit_plan* p, int64_t T) {
-    if (!(p->bp.ok && p->bp.wave_ok) || p->tune.wave_history == 1 || T < 2) return false;
+    if (!(p->bp.ok && p->bp.wave_ok) || p->tune.wave_history != 2 || T < 2) return false;
     vit::BtArgs b{};
     b.S = p->S;
     b.SP = p->L.SP;
@@ -290,7 +290,7 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
     if (family < 0) return family;
     const Tuning& tn = plan->tune;
     const bool half = family == 3 && wave_half_applies(plan, T);
-    if (family == 3 && tn.wave_history == 2 && !half) return VIT_EUNSUPPORTED;
+    if (family == 3 && tn.wave_history == 2 && !half && T >= 2) return VIT_EUNSUPPORTED;
     const WsLayout w = ws_layout_family(plan, family, B, T);
     if (workspace_bytes < w.bytes) return VIT_EWORKSPACE;
     if (B == 0) return VIT_OK;
@@ -450,8 +450,6 @@ int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* len
         hipError_t ez = hipMemsetAsync(b.counters, 0, (size_t)B * vit::kBtCounters * sizeof(int32_t), (hipStream_t)stream);
         if (ez != hipSuccess) return hip_fail(ez);
     }
-    b.pair_ok = vit::pair_backtrace_plan_ok(plan->bp) ? 1 : 0;
-    b.off_tabH = plan->L.off_tabH;
     if (st.half) {
         b.hist_half = 1;
         b.hist_rows = (T + 1) / 2;
@@ -459,18 +457,6 @@ int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* len
         b.xcol0_odd = 2 + b.n_extras;
         b.logE = st.logE;
         b.e_f16 = st.e_f16;
-    }
-    // speculative pass with two (song, chunk) streams per wave where the band allows it, then the verify-and-repair pass of the
-    // one-stream kernel for this history layout
-    if (b.bt_form == 0 && vit::pair_backtrace_applies(b) && (st.half ? vit::half_backtrace_applies(b) : vit::sparse_backtrace_applies(b))) {
-        b.chunks = vit::pair_backtrace_chunks(B, (int)T);
-        b.warm = vit::kBtWarmSparse;
-        if (tn.bt_chunks >= 1 && tn.bt_chunks <= vit::kBtMaxChunks) b.chunks = tn.bt_chunks;
-        if (tn.bt_warm >= 0) b.warm = tn.bt_warm;
-        hipError_t ep = vit::launch_backtrace_pair(b, (hipStream_t)stream);
-        if (ep == hipSuccess && b.chunks > 1)
-            ep = st.half ? vit::launch_backtrace_half(b, (hipStream_t)stream, 2) : vit::launch_backtrace_sparse(b, (hipStream_t)stream, 2);
-        return ep == hipSuccess ? VIT_OK : hip_fail(ep);
     }
     if (st.half) {
         b.chunks = vit::sparse_backtrace_chunks(B, (int)T);
@@ -480,7 +466,7 @@ int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* len
         hipError_t eh = vit::launch_backtrace_half(b, (hipStream_t)stream);
         return eh == hipSuccess ? VIT_OK : hip_fail(eh);
     }
-    const bool sparse = (b.bt_form == 0 || b.bt_form == 3 || b.bt_form == 4) && vit::sparse_backtrace_applies(b);
+    const bool sparse = b.bt_form == 0 && vit::sparse_backtrace_applies(b);
     b.chunks = sparse ? vit::sparse_backtrace_chunks(B, (int)T) : vit::backtrace_chunks(B, (int)T);
     b.warm = sparse ? vit::kBtWarmSparse : vit::kBtWarm;
     // test hooks (vit_plan_set_option): force the chunking / warm-up so that the verify-and-repair pass is exercised

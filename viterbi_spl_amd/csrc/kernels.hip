@@ -2597,7 +2597,7 @@ int backtrace_chunks(int64_t B, int T) {
 }
 
 hipError_t launch_backtrace(BtArgs a, hipStream_t st) {
-    if ((a.bt_form == 0 || a.bt_form == 3 || a.bt_form == 4) && sparse_backtrace_applies(a)) return launch_backtrace_sparse(a, st);
+    if (a.bt_form == 0 && sparse_backtrace_applies(a)) return launch_backtrace_sparse(a, st);
     a.K = backtrace_tile_rows(a.SD);
     const int nwt = (a.S + 63) / 64;
     if (nwt <= 2) return launch_bt_t<2>(a, st);

@@ -80,8 +80,7 @@ struct BtArgs {
     int chunks, warm;       // time-parallel back-trace: chunks per song, warm-up frames
     int banded;             // 1: row structure (window / c0 / extras / dense rows) proven by the plan
     int have_fmax;          // the forward pass was a banded kernel (it fills pad column S of the history rows)
-    int bt_form;            // 0 auto (two streams per wave, else sparse fetch, where they apply) | 1 generic (lazy) kernel | 2 whole-row kernels
-                            // | 3 sparse fetch, one stream per wave
+    int bt_form;            // 0 auto (sparse fetch where it applies) | 1 generic (lazy) kernel | 2 whole-row kernels
     int lo_affine, lo_off;  // lo[j] == clamp(j - lo_off, 0, S - W)
     int dense_rows[kMaxDenseRows];
     int n_extras, n_dense;
@@ -98,8 +97,6 @@ struct BtArgs {
     const void* logE;       // [B,T,S] the tensor vit_forward decoded (f32 or f16)
     int e_f16;
     int32_t* counters;      // [B][kBtCounters] per-song event counts of the sparse / half / half-wave kernels (zeroed by vit_backtrace)
-    int pair_ok;            // the plan built tabH (plan.hpp pair_backtrace_plan_ok)
-    size_t off_tabH;
 };
 
 hipError_t launch_dense(const FwdArgs& a, int songs_per_group, bool f16, hipStream_t st);
@@ -117,10 +114,6 @@ hipError_t launch_backtrace_sparse(const BtArgs& a, hipStream_t st, int phases =
 // backtrace_half.hip: the same for a half history (wave form, even rows only): odd frames are rebuilt from the row before them
 bool half_backtrace_applies(const BtArgs& a);
 hipError_t launch_backtrace_half(const BtArgs& a, hipStream_t st, int phases = 3);
-// backtrace_pair.hip: the speculative pass with two (song, chunk) streams per wave (band within 14 sources of the target)
-bool pair_backtrace_applies(const BtArgs& a);
-hipError_t launch_backtrace_pair(const BtArgs& a, hipStream_t st);
-int pair_backtrace_chunks(int64_t B, int T);
 int sparse_backtrace_chunks(int64_t B, int T);
 hipError_t launch_voicing_map(const int32_t* states, int64_t n, int32_t n_bins, uint8_t* voiced, int32_t* bins,
                               hipStream_t st);
@@ -138,10 +131,10 @@ int backtrace_tile_rows(int SD);
 constexpr int kBtWarm = 128;       // warm-up frames of a speculative chunk (survivor paths coalesce within tens of frames)
 constexpr int kBtWarmSparse = 64;  // the sparse kernel runs many short chunks: a shorter warm-up (a wrong guess only costs a repair)
 constexpr int kBtMaxChunks = 32;
-// per-song event counters (include/viterbi_hip.h vit_backtrace_counters): tiles fetched, tiles taken from the prefetch, span
-// misses, whole-row evaluations (bound failures), of those: odd rows rebuilt in full, chunks repaired, frames rewritten by repairs
+// per-song event counters (include/viterbi_hip.h vit_backtrace_counters): tiles fetched, span misses, whole-row evaluations
+// (bound failures), of those: odd rows rebuilt in full, chunks repaired, frames rewritten by repairs
 constexpr int kBtCounters = 16;
-enum { kCtTiles = 0, kCtPrefetched = 1, kCtMisses = 2, kCtFullRows = 3, kCtRebuilt = 4, kCtRepairs = 5, kCtRepairFrames = 6 };
+enum { kCtTiles = 0, kCtMisses = 1, kCtFullRows = 2, kCtRebuilt = 3, kCtRepairs = 4, kCtRepairFrames = 5 };
 int backtrace_chunks(int64_t B, int T);
 
 }  // namespace vit

@@ -240,8 +240,6 @@ ImageLayout make_layout(int S, const BandedPlan& bp) {
     L.off_stepC = off;  off = align256(off + sizeof(float) * (size_t)(kMaxStepBands + 1) * L.SP);
     L.off_tabV = off;
     if (bp.ok && bp.wave_ok) off = align256(off + sizeof(float) * (size_t)bp.wave_npl * wave_pairs(bp.wave_dk) * 2 * 64);
-    L.off_tabH = off;
-    if (pair_backtrace_plan_ok(bp)) off = align256(off + sizeof(float) * (size_t)L.SP * kPairRow);
     L.bytes = off;
     return L;
 }
@@ -296,20 +294,6 @@ void fill_image(const float* A, const float* log_pi, const BandedPlan& bp, const
             for (int w = 0; w < L.W; ++w) row[w] = A[(size_t)j * S + bp.lo[j] + w];
             for (int k = 0; k < bp.n_extras; ++k) row[L.W + k] = A[(size_t)j * S + bp.extras[k]];
             row[L.W + kMaxExtras] = bp.rowc[j];
-        }
-    }
-    if (pair_backtrace_plan_ok(bp)) {   // candidate rows of the half-wave back-trace
-        float* th = reinterpret_cast<float*>(image + L.off_tabH);
-        for (int j = 0; j < SP; ++j) {
-            float* row = th + (size_t)j * kPairRow;
-            for (int c = 0; c < kPairRow; ++c) row[c] = ninf;
-            if (j >= S) continue;
-            for (int c = 0; c <= 2 * kPairD; ++c) {
-                const int i = j - kPairD + c;
-                if (i >= 0 && i < S) row[c] = A[(size_t)j * S + i];
-            }
-            for (int k = 0; k < bp.n_extras; ++k) row[2 * kPairD + 1 + k] = A[(size_t)j * S + bp.extras[k]];
-            row[31] = bp.rowc[j];
         }
     }
     if (bp.wave_ok) {   // weights in the order wave_forward_kernel loads them: [own state k][pair m][half h][lane]

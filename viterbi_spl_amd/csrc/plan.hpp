@@ -70,15 +70,6 @@ struct BandedPlan {
 };
 
 constexpr int kWaveMaxExtras = 2;
-
-// "Half-wave" back-trace (backtrace_pair.hip): 32 lanes decide one frame -- the 2*kPairD + 1 band sources j - kPairD .. j + kPairD
-// of the path state j, two extra columns and the bound -- so a wavefront walks two (song, chunk) streams at once.  Applies
-// to banded plans without dense rows whose exception spans lie within kPairD of the target (BandedPlan::wave_d) and with at
-// most two extra columns.  tabH[j][c]: c < 29 logA_T[j][j - 14 + c] (-inf where that source does not exist), c = 29, 30 the
-// extra columns (-inf beyond n_extras), c = 31 the row constant; row stride kPairRow floats (odd: conflict-free by row AND by column).
-constexpr int kPairD = 14;
-constexpr int kPairRow = 33;
-inline bool pair_backtrace_plan_ok(const BandedPlan& bp) { return bp.ok && bp.n_dense == 0 && bp.wave_d <= kPairD && bp.n_extras <= 2; }
 // half-width the wave kernel is instantiated for, given the states per lane and the proven half-width (0: none)
 constexpr int wave_table_d(int npl, int d) { return (npl == 6 && d <= 14) ? 14 : 0; }
 constexpr int wave_pairs(int dk) { return dk + 1; }   // packed source pairs per target: 2*dk + 1 sources, even-aligned
@@ -113,7 +104,6 @@ struct ImageLayout {
     size_t off_tabX = 0;     // float [SP][W+5]     per target: W window entries, 4 extra-column entries, row constant (back-trace)
     size_t off_stepC = 0;    // float [16][SP]      step-structure band values per source (step_ok)
     size_t off_tabV = 0;     // float [npl][dk+1][2][64]  wave form: weights of lane l, own state k, source pair m, half h
-    size_t off_tabH = 0;     // float [SP][kPairRow]  half-wave back-trace candidates (pair_backtrace_plan_ok)
     size_t bytes = 0;
 };
 

@@ -101,6 +101,12 @@ class ViterbiDecoder:
             raise _lib.ViterbiHipError(f"algo {algo!r} is not available for this plan")
         return need
 
+    def history_mode(self, B: int, T: int, algo: str = "auto") -> str:
+        """"half" if the forward kernel `algo` resolves to for this batch stores only the delta rows of even frames (the wave form;
+        the back-trace rebuilds the odd ones), else "full" -- read off the workspace the library asks for."""
+        need = self.workspace_bytes(B, T, algo)
+        return "half" if need * 1.5 < self.workspace_bytes(B, T) else "full"
+
     def _workspace(self, B: int, T: int, slot: int = 0, algo: Optional[str] = None) -> Tuple[int, int]:
         """Workspace `slot` (callers that overlap the back-trace of one batch with the forward pass of the next on
         two streams give each batch in flight its own slot; slot 0 is the default).  A buffer that is already large
@@ -173,8 +179,7 @@ class ViterbiDecoder:
                 raise ValueError(phase)
         _lib.check(rc, f"vit_{phase if phase != 'both' else 'decode'}")
 
-    COUNTERS = ("tiles_fetched", "tiles_prefetched", "span_misses", "whole_row_evaluations", "odd_rows_rebuilt",
-                "chunks_repaired", "frames_repaired")
+    COUNTERS = ("tiles_fetched", "span_misses", "whole_row_evaluations", "odd_rows_rebuilt", "chunks_repaired", "frames_repaired")
 
     def backtrace_counters(self, B: int, T: int, slot: int = 0) -> dict:
         """Event counts of the last back-trace that ran on workspace `slot` (``vit_backtrace_counters``), summed over the songs.
