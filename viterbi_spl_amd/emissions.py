@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import math
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -70,9 +71,14 @@ def softmax_scaled_log_emissions(logits: torch.Tensor, voicing_threshold_prob: f
             raise ValueError(f"prior must be a contiguous float32 [{n_bins + 1}] tensor on the logits' device")
     out = torch.empty(logits.shape[:-1] + (n_bins + 1,), dtype=torch.float32, device=logits.device)
     n = logits.numel() // n_bins
+    # the reference pads with log(vth / (1. - vth)) computed from an np.float32 scalar (dcnet/softmax_viterbi.py:2546-2548): float32
+    # arithmetic under NumPy >= 2 -- the NumPy that generated tests/golden/obs_goldens.npz -- (NumPy 1.x promoted the scalar
+    # expression to float64 before the float32 pad: at most one ulp apart); hand the kernel exactly the float32 value
+    vth = np.float32(voicing_threshold_prob)
+    unvoiced_logit = float(np.log(vth / (np.float32(1) - vth)))
     with torch.cuda.device(logits.device):
         rc = _lib.load().vit_obs_softmax_scaled(logits.data_ptr(), n, n_bins, single_side_peak_width,
-                                                math.log(voicing_threshold_prob / (1.0 - voicing_threshold_prob)),
+                                                unvoiced_logit,
                                                 prior.data_ptr() if prior is not None else None, out.data_ptr(),
                                                 torch.cuda.current_stream(logits.device).cuda_stream)
     _lib.check(rc, "vit_obs_softmax_scaled")

@@ -271,18 +271,26 @@ class RecordingAccumulator:
     """Per-recording logits kept on the GPU (replaces tonet/for_paper.py:2282-2309, where every batch of snippets is
     copied to the host, transposed, and the recording concatenated in NumPy before ``viterbi(logits)``).
 
-        acc = RecordingAccumulator(viterbi, max_frames)          # viterbi: Viterbi ("shaun") or SoftMaxViterbi
-        for batch in recording: acc.append(pitch_logits, padded_frames)   # [n_snippets, n_bins+1, frames] on the GPU
+        acc = RecordingAccumulator(viterbi, max_frames)          # viterbi: Viterbi ("shaun"), SoftMaxViterbi or ScaledSoftMaxViterbi
+        for batch in recording: acc.append(pitch_logits, padded_frames)   # [n_snippets, channels, frames] on the GPU
         voiced, bins, notes = acc.finish(note_range)             # torch tensors on the GPU
 
     ``append`` transposes the snippets into time-major rows directly behind the rows already held (one kernel:
     ``vit_snippets_append``; "shaun" rows are relative to the unvoiced channel, :2296-2297), ``finish`` runs emission
-    builder, decoder, voicing map and the bin -> note gather without a host visit."""
+    builder, decoder, voicing map and the bin -> note gather without a host visit.  Channels per snippet: n_bins + 1 with the
+    unvoiced channel first for Viterbi (subtracted and dropped) and SoftMaxViterbi (kept); the n_bins pitch channels only for
+    ScaledSoftMaxViterbi, whose unvoiced logit is a constant (dcnet/softmax_viterbi.py:2548-2550)."""
 
     def __init__(self, viterbi: _PreparedViterbi, max_frames: int):
         self.viterbi = viterbi
-        self.mode = 0 if isinstance(viterbi, Viterbi) else 1
-        self.cols = viterbi.num_freq_bins + (0 if self.mode == 0 else 1)
+        if isinstance(viterbi, Viterbi):
+            self.mode, self.channels, self.cols = 0, viterbi.num_freq_bins + 1, viterbi.num_freq_bins
+        elif isinstance(viterbi, ScaledSoftMaxViterbi):       # (a SoftMaxViterbi subclass: test it first)
+            self.mode, self.channels, self.cols = 1, viterbi.num_freq_bins, viterbi.num_freq_bins
+        elif isinstance(viterbi, SoftMaxViterbi):
+            self.mode, self.channels, self.cols = 1, viterbi.num_freq_bins + 1, viterbi.num_freq_bins + 1
+        else:
+            raise TypeError("RecordingAccumulator needs a Viterbi, SoftMaxViterbi or ScaledSoftMaxViterbi")
         dev = viterbi._decoder.device
         self._rows = torch.empty((int(max_frames), self.cols), dtype=torch.float32, device=dev)
         self.n_frames = 0
@@ -294,8 +302,8 @@ class RecordingAccumulator:
         from . import _lib
         if not isinstance(pitch_logits, torch.Tensor) or pitch_logits.device != self._rows.device:
             raise ValueError("pitch_logits must be a torch tensor on the decoder's device")
-        if pitch_logits.dtype != torch.float32 or pitch_logits.dim() != 3 or pitch_logits.shape[1] != self.viterbi.num_freq_bins + 1:
-            raise ValueError(f"pitch_logits must be float32 [snippets, {self.viterbi.num_freq_bins + 1}, frames]")
+        if pitch_logits.dtype != torch.float32 or pitch_logits.dim() != 3 or pitch_logits.shape[1] != self.channels:
+            raise ValueError(f"pitch_logits must be float32 [snippets, {self.channels}, frames]")
         x = pitch_logits.contiguous()
         n, C, F = x.shape
         rows = n * F - int(padded_frames)
