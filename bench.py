@@ -368,6 +368,26 @@ def extra_blocks(dev, args):
         sweep[f"B{B}_ragged"]["forward_ms_if_all_full_length"] = sweep[f"B{B}"]["forward_ms"] if f"B{B}" in sweep else None
         del E
         torch.cuda.empty_cache()
+    # bounded-workspace decode (vit_decode_checkpointed): checkpoint rows in pass 1, segments of 1024 frames re-run and back-traced
+    B, K = 256, 1024
+    E = tiled_emissions(synth.emissions_peaks, B, T, 361, 1234, dev, torch.float32)
+    need = dec.workspace_bytes_checkpointed(B, T, K)
+    ws = torch.empty(need + 256, dtype=torch.uint8, device=dev)
+    want_s, want_l = dec.decode(E, algo="banded", out_dtype=torch.int32)
+    st, ll = dec.decode_checkpointed(E, segment_frames=K, out_dtype=torch.int32, workspace=ws)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        st, ll = dec.decode_checkpointed(E, segment_frames=K, out_dtype=torch.int32, workspace=ws)
+    torch.cuda.synchronize()
+    ck_ms = (time.perf_counter() - t0) / 3 * 1e3
+    sweep["B256_checkpointed"] = {"songs": B, "segment_frames": K, "ms_per_step": ck_ms, "Mframes_per_s": B * T / ck_ms / 1e3,
+                                  "workspace_GB": need / 1e9, "workspace_GB_full_history": dec.workspace_bytes(B, T) / 1e9,
+                                  "equals_normal_decode": bool(torch.equal(st, want_s) and torch.equal(ll, want_l)),
+                                  "note": "wall clock of 3 whole calls (pass 1 + 30 segments x (forward, prep, back-trace)), wave form"}
+    del E, ws, st, ll, want_s, want_l
+    dec._ws = None
+    torch.cuda.empty_cache()
     out["sweep"] = {"workload": f"T={T}, S=361, fp32 log-emissions (peaks unless the row says dense), tonet transition; songs repeat with period 32; "
                                 f"{NS} timed steps per row: forward + back-trace back to back on one stream (forward_ms, backtrace_ms, Mframes_per_s) and "
                                 "the two-stream schedule of the headline (overlapped_*); *_hbm_frac on algorithmic bytes (SURVEY 8d); "

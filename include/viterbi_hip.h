@@ -163,6 +163,20 @@ int vit_forward(const vit_plan *plan, const void *logE, int emis_dtype, int64_t 
 int vit_backtrace(const vit_plan *plan, int64_t B, int64_t T, const int64_t *lengths,
                   void *workspace, size_t workspace_bytes, int32_t *states, int algo, vit_stream stream);
 
+/*
+ * Bounded-workspace decode: the same result as vit_decode() with a workspace of about (T / segment_frames + segment_frames)
+ * delta rows per song instead of T (the reference keeps its work buffers T1 / T2 for one song at a time,
+ * tonet/for_paper.py:1852-1853; vit_decode keeps a history for the whole batch).  Pass 1 runs the forward recursion and keeps
+ * one row per segment of segment_frames frames; pass 2 re-runs it segment by segment from the last to the first and
+ * back-traces each.  Exact by construction; about twice the forward work.  Plans with the wave form only (vit_plan_info
+ * reserved[2] bit 3; VIT_EUNSUPPORTED otherwise); 64 <= segment_frames.  The library does not record this call for
+ * vit_backtrace().
+ */
+size_t vit_workspace_bytes_checkpointed(const vit_plan *plan, int64_t B, int64_t T, int64_t segment_frames);
+int vit_decode_checkpointed(const vit_plan *plan, const void *logE, int emis_dtype, int64_t B, int64_t T,
+                            const int64_t *lengths, void *workspace, size_t workspace_bytes, int32_t *states,
+                            float *loglik, int64_t segment_frames, vit_stream stream);
+
 /* Event counts of the last vit_backtrace() on this workspace (banded plans; all zero for the kernels that do not count):
  * *offset = byte offset, inside the workspace, of an int32 [B][*n_per_song] device array (valid once the back-trace has run
  * on its stream): per song [0] tiles fetched, [1] span misses (the path left the fetched columns), [2] whole-row evaluations

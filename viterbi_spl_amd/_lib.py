@@ -20,7 +20,7 @@ EXPORTS = (
     "vit_abi_version", "vit_status_string", "vit_last_hip_error", "vit_plan_create", "vit_plan_destroy",
     "vit_plan_query", "vit_plan_image_bytes", "vit_plan_upload", "vit_workspace_bytes", "vit_decode",
     "vit_forward", "vit_backtrace", "vit_voicing_map", "vit_obs_shaun", "vit_obs_softmax", "vit_obs_softmax_scaled", "vit_plan_set_option", "vit_snippets_append", "vit_voicing_notes",
-    "vit_workspace_bytes_for", "vit_debug_scan", "vit_backtrace_counters",
+    "vit_workspace_bytes_for", "vit_debug_scan", "vit_backtrace_counters", "vit_workspace_bytes_checkpointed", "vit_decode_checkpointed",
 )
 ABI_VERSION = 3
 
@@ -80,6 +80,10 @@ def load() -> ctypes.CDLL:
     lib.vit_workspace_bytes.argtypes = [vp, i64, i64]
     lib.vit_workspace_bytes_for.restype = sz
     lib.vit_workspace_bytes_for.argtypes = [vp, i64, i64, i32]
+    lib.vit_workspace_bytes_checkpointed.restype = sz
+    lib.vit_workspace_bytes_checkpointed.argtypes = [vp, i64, i64, i64]
+    lib.vit_decode_checkpointed.restype = i32
+    lib.vit_decode_checkpointed.argtypes = [vp, vp, i32, i64, i64, vp, vp, sz, vp, vp, i64, vp]
     lib.vit_backtrace_counters.restype = i32
     lib.vit_backtrace_counters.argtypes = [vp, i64, i64, vp, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_int32)]
     lib.vit_decode.restype = i32

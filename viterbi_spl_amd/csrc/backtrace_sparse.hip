@@ -95,9 +95,10 @@ __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
     const int song = MODE == 0 ? gw / C : gw;
     const int chunk = MODE == 0 ? gw % C : 0;
     if (song >= a.B) return;
+    if (a.skip_nonpositive && a.lengths[song] < 1) return;        // segment of a checkpointed decode this song does not reach
     const int Tb = sp_song_length(a.lengths, song, T);
-    int32_t* __restrict__ states = a.states + (size_t)song * T;
-    const float* __restrict__ hist = a.hist + (size_t)song * T * SD;
+    int32_t* __restrict__ states = a.states + (size_t)song * a.states_stride;
+    const float* __restrict__ hist = a.hist + (size_t)song * a.hist_rows * SD;
     float* tile = tiles + wv * kSpK * kSpRS;
 
     // ---- per-lane constants, per candidate slot: candidates 0 .. W-1 the window, W .. W+nx-1 the extra columns, CB the bound

@@ -272,41 +272,10 @@ static int resolve_family(const vit_plan* plan, int algo, int64_t B) {
     return algo == VIT_ALGO_AUTO ? 1 : VIT_EUNSUPPORTED;
 }
 
-size_t vit_workspace_bytes_for(const vit_plan* plan, int64_t B, int64_t T, int algo) {
-    if (!plan || B < 0 || T < 1) return 0;
-    const int family = resolve_family(plan, algo, B);
-    if (family < 0) return 0;
-    return ws_layout_family(plan, family, B, T).bytes;
-}
-
-int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t B, int64_t T,
-                const int64_t* lengths, void* workspace, size_t workspace_bytes, float* loglik, int algo,
-                vit_stream stream) {
-    int rc = check_common(plan, B, T, workspace);
-    if (rc != VIT_OK) return rc;
-    if (!logE) return VIT_EINVAL;
-    if (emis_dtype != VIT_F32 && emis_dtype != VIT_F16) return VIT_EINVAL;
-    const int family = resolve_family(plan, algo, B);
-    if (family < 0) return family;
+// the fields of FwdArgs that depend on the plan and its options only
+static void fwd_args_from_plan(const vit_plan* plan, vit::FwdArgs& a) {
     const Tuning& tn = plan->tune;
-    const bool half = family == 3 && wave_half_applies(plan, T);
-    if (family == 3 && tn.wave_history == 2 && !half && T >= 2) return VIT_EUNSUPPORTED;
-    const WsLayout w = ws_layout_family(plan, family, B, T);
-    if (workspace_bytes < w.bytes) return VIT_EWORKSPACE;
-    if (B == 0) return VIT_OK;
-    stamp_erase(plan, workspace);      // whatever this workspace held is gone once the kernel below starts; re-stamped on success
-
-    uint8_t* ws = static_cast<uint8_t*>(workspace);
-    vit::FwdArgs a{};
     a.image = plan->dev_image;
-    a.logE = logE;
-    a.lengths = lengths;
-    a.hist = reinterpret_cast<float*>(ws + w.off_hist);
-    a.fmax = reinterpret_cast<float*>(ws + w.off_fmax);
-    a.last_state = reinterpret_cast<int32_t*>(ws + w.off_last);
-    a.loglik = loglik;
-    a.B = B;
-    a.T = (int)T;
     a.S = plan->S;
     a.SP = plan->L.SP;
     a.S4 = plan->L.S4;
@@ -344,11 +313,50 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
     a.wave_npl = plan->bp.wave_npl;
     a.wave_dk = plan->bp.wave_dk;
     a.wave_flags = tn.wave_two == 1 ? 1 : (tn.wave_two == 2 ? 2 : 0);
-    a.hist_half = half ? 1 : 0;
-    a.hist_rows = half ? (T + 1) / 2 : T;
     a.win_shift = (plan->bp.ok && plan->bp.lo_affine) ? (plan->bp.lo_off & 3) : 0;
     a.win_shift2 = (plan->bp.ok && plan->bp.pair_ok && plan->bp.lo2_affine) ? (plan->bp.lo2_off & 3) : 0;
     if (tn.win_shift >= 0) a.win_shift = a.win_shift2 = tn.win_shift & 3;   // every value is functionally correct
+}
+
+size_t vit_workspace_bytes_for(const vit_plan* plan, int64_t B, int64_t T, int algo) {
+    if (!plan || B < 0 || T < 1) return 0;
+    const int family = resolve_family(plan, algo, B);
+    if (family < 0) return 0;
+    return ws_layout_family(plan, family, B, T).bytes;
+}
+
+int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t B, int64_t T,
+                const int64_t* lengths, void* workspace, size_t workspace_bytes, float* loglik, int algo,
+                vit_stream stream) {
+    int rc = check_common(plan, B, T, workspace);
+    if (rc != VIT_OK) return rc;
+    if (!logE) return VIT_EINVAL;
+    if (emis_dtype != VIT_F32 && emis_dtype != VIT_F16) return VIT_EINVAL;
+    const int family = resolve_family(plan, algo, B);
+    if (family < 0) return family;
+    const Tuning& tn = plan->tune;
+    const bool half = family == 3 && wave_half_applies(plan, T);
+    if (family == 3 && tn.wave_history == 2 && !half && T >= 2) return VIT_EUNSUPPORTED;
+    const WsLayout w = ws_layout_family(plan, family, B, T);
+    if (workspace_bytes < w.bytes) return VIT_EWORKSPACE;
+    if (B == 0) return VIT_OK;
+    stamp_erase(plan, workspace);      // whatever this workspace held is gone once the kernel below starts; re-stamped on success
+
+    uint8_t* ws = static_cast<uint8_t*>(workspace);
+    vit::FwdArgs a{};
+    fwd_args_from_plan(plan, a);
+    a.logE = logE;
+    a.lengths = lengths;
+    a.hist = reinterpret_cast<float*>(ws + w.off_hist);
+    a.fmax = reinterpret_cast<float*>(ws + w.off_fmax);
+    a.last_state = reinterpret_cast<int32_t*>(ws + w.off_last);
+    a.loglik = loglik;
+    a.B = B;
+    a.T = (int)T;
+    a.hist_half = half ? 1 : 0;
+    a.hist_rows = half ? (T + 1) / 2 : T;
+    a.t_begin = 0;
+    a.t_end = (int)T;
 
     FwdStamp st;
     st.ws = workspace;
@@ -386,42 +394,18 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
     return VIT_OK;
 }
 
-int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* lengths, void* workspace,
-                  size_t workspace_bytes, int32_t* states, int algo, vit_stream stream) {
-    int rc = check_common(plan, B, T, workspace);
-    if (rc != VIT_OK) return rc;
-    if (!states) return VIT_EINVAL;
-    (void)algo;   // kept for ABI compatibility: the layout comes from what vit_forward recorded for this workspace
-    if (B == 0) return VIT_OK;
-    FwdStamp st;
-    if (!stamp_get(plan, workspace, &st) || st.B != B || st.T != T) return VIT_ENOFORWARD;   // no matching vit_forward
-    const Tuning& tn = plan->tune;
-    const WsLayout w = st.half ? ws_layout_hist(B, (size_t)((T + 1) / 2), (size_t)st.SD) : ws_layout_hist(B, (size_t)T, (size_t)st.SD);
-    if (workspace_bytes < w.bytes) return VIT_EWORKSPACE;
-    uint8_t* ws = static_cast<uint8_t*>(workspace);
-    vit::BtArgs b{};
+// the fields of BtArgs that depend on the plan and its options only
+static void bt_args_from_plan(const vit_plan* plan, vit::BtArgs& b) {
     b.image = plan->dev_image;
-    b.hist = reinterpret_cast<const float*>(ws + w.off_hist);
-    b.last_state = reinterpret_cast<const int32_t*>(ws + w.off_last);
-    b.lengths = lengths;
-    b.states = states;
-    b.entry = reinterpret_cast<int32_t*>(ws + w.off_entry);
-    b.B = B;
-    b.T = (int)T;
     b.S = plan->S;
     b.SP = plan->L.SP;
-    b.SD = st.SD;
-    b.col0 = st.col0;
-    b.mcol = st.mcol;
-    b.xcol0 = st.xcol0;
     b.W = plan->bp.ok ? plan->bp.W : 0;
     b.banded = plan->bp.ok ? 1 : 0;
     b.n_extras = plan->bp.ok ? plan->bp.n_extras : 0;
     b.n_dense = plan->bp.ok ? plan->bp.n_dense : 0;
     for (int k = 0; k < vit::kMaxExtras; ++k) b.extras[k] = plan->bp.extras[k];
     b.c0 = plan->bp.c0;
-    b.have_fmax = st.have_fmax;
-    b.bt_form = tn.backtrace_form;
+    b.bt_form = plan->tune.backtrace_form;
     b.lo_affine = plan->bp.lo_affine ? 1 : 0;
     b.lo_off = plan->bp.lo_off;
     for (int d = 0; d < vit::kMaxDenseRows; ++d) b.dense_rows[d] = d < plan->bp.n_dense ? plan->bp.dense_rows[d] : -1;
@@ -442,6 +426,36 @@ int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* len
     b.off_denseA = plan->L.off_denseA;
     b.off_Arow = plan->L.off_Arow;
     b.off_rowc = plan->L.off_rowc;
+}
+
+int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* lengths, void* workspace,
+                  size_t workspace_bytes, int32_t* states, int algo, vit_stream stream) {
+    int rc = check_common(plan, B, T, workspace);
+    if (rc != VIT_OK) return rc;
+    if (!states) return VIT_EINVAL;
+    (void)algo;   // kept for ABI compatibility: the layout comes from what vit_forward recorded for this workspace
+    if (B == 0) return VIT_OK;
+    FwdStamp st;
+    if (!stamp_get(plan, workspace, &st) || st.B != B || st.T != T) return VIT_ENOFORWARD;   // no matching vit_forward
+    const Tuning& tn = plan->tune;
+    const WsLayout w = st.half ? ws_layout_hist(B, (size_t)((T + 1) / 2), (size_t)st.SD) : ws_layout_hist(B, (size_t)T, (size_t)st.SD);
+    if (workspace_bytes < w.bytes) return VIT_EWORKSPACE;
+    uint8_t* ws = static_cast<uint8_t*>(workspace);
+    vit::BtArgs b{};
+    b.hist = reinterpret_cast<const float*>(ws + w.off_hist);
+    b.last_state = reinterpret_cast<const int32_t*>(ws + w.off_last);
+    b.lengths = lengths;
+    b.states = states;
+    b.entry = reinterpret_cast<int32_t*>(ws + w.off_entry);
+    b.B = B;
+    b.T = (int)T;
+    bt_args_from_plan(plan, b);
+    b.SD = st.SD;
+    b.col0 = st.col0;
+    b.mcol = st.mcol;
+    b.xcol0 = st.xcol0;
+    b.have_fmax = st.have_fmax;
+    b.states_stride = T;
     if (st.family == 3 && !(b.banded && b.n_dense == 0)) return VIT_EINVAL;   // (cannot happen: wave_ok implies both)
     b.hist_rows = T;
     b.counters = nullptr;
@@ -493,6 +507,132 @@ int vit_decode(const vit_plan* plan, const void* logE, int emis_dtype, int64_t B
     int rc = vit_forward(plan, logE, emis_dtype, B, T, lengths, workspace, workspace_bytes, loglik, algo, stream);
     if (rc != VIT_OK) return rc;
     return vit_backtrace(plan, B, T, lengths, workspace, workspace_bytes, states, algo, stream);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Bounded-workspace decode (wave-form plans).  The reference keeps T1 / T2 for ONE song (tonet/for_paper.py:1852-1853); the
+// batched decode above keeps a delta history for the whole batch (46 MB per song at T = 30000).  Here the history never
+// exists at once: pass 1 runs the forward recursion over all T frames and keeps one delta row per segment of K frames (the row
+// in front of the segment) plus the terminal state; pass 2 walks the segments from the last to the first, re-runs the
+// forward kernel over one segment from its checkpoint row into a K-row buffer and back-traces it from the state the segment
+// behind it decided at its first frame.  Exact by construction (the same kernels, the same sums); twice the forward work.
+namespace {
+
+struct CkLayout {
+    int64_t nseg;
+    size_t off_ckpt, off_seg, off_cnt, off_last, off_entry, off_slen, off_slast, bytes;
+};
+CkLayout ck_layout(const vit_plan* p, int64_t B, int64_t T, int64_t K) {
+    CkLayout c;
+    const size_t sd = (size_t)vit::wave_hist_stride(p->bp.wave_npl) * sizeof(float);
+    c.nseg = (T + K - 1) / K;
+    c.off_ckpt = 0;                                                              // [B][nseg] rows: nseg - 1 checkpoints + the scratch row
+    c.off_seg = align256((size_t)B * (size_t)c.nseg * sd);                       // [B][K + 1] rows of the segment being walked
+    c.off_cnt = c.off_seg + align256((size_t)B * (size_t)(K + 1) * sd);
+    c.off_last = c.off_cnt + align256((size_t)B * 64 * sizeof(float));
+    c.off_entry = c.off_last + align256((size_t)B * sizeof(int32_t));
+    c.off_slen = c.off_entry + align256((size_t)B * vit::kBtMaxChunks * sizeof(int32_t));
+    c.off_slast = c.off_slen + align256((size_t)B * sizeof(int64_t));
+    c.bytes = c.off_slast + align256((size_t)B * sizeof(int32_t));
+    return c;
+}
+bool ck_supported(const vit_plan* p, int64_t K) { return p->bp.ok && p->bp.wave_ok && K >= 64 && K <= (int64_t)1 << 24; }
+
+}  // namespace
+
+size_t vit_workspace_bytes_checkpointed(const vit_plan* plan, int64_t B, int64_t T, int64_t segment_frames) {
+    if (!plan || B < 0 || T < 1 || !ck_supported(plan, segment_frames)) return 0;
+    return ck_layout(plan, B, T, segment_frames).bytes;
+}
+
+int vit_decode_checkpointed(const vit_plan* plan, const void* logE, int emis_dtype, int64_t B, int64_t T, const int64_t* lengths,
+                            void* workspace, size_t workspace_bytes, int32_t* states, float* loglik, int64_t segment_frames,
+                            vit_stream stream) {
+    int rc = check_common(plan, B, T, workspace);
+    if (rc != VIT_OK) return rc;
+    if (!logE || !states) return VIT_EINVAL;
+    if (emis_dtype != VIT_F32 && emis_dtype != VIT_F16) return VIT_EINVAL;
+    const int64_t K = segment_frames;
+    if (!ck_supported(plan, K)) return K < 64 || K > (int64_t)1 << 24 ? VIT_EINVAL : VIT_EUNSUPPORTED;
+    const CkLayout c = ck_layout(plan, B, T, K);
+    if (workspace_bytes < c.bytes) return VIT_EWORKSPACE;
+    if (B == 0) return VIT_OK;
+    stamp_erase(plan, workspace);
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t* ws = static_cast<uint8_t*>(workspace);
+    const bool f16 = emis_dtype == VIT_F16;
+    const int SDW = vit::wave_hist_stride(plan->bp.wave_npl);
+    hipError_t e;
+    if (lengths) {     // frames past a song's end: -1 (segments a song does not reach are skipped, not written)
+        e = hipMemsetAsync(states, 0xff, (size_t)B * (size_t)T * sizeof(int32_t), st);
+        if (e != hipSuccess) return hip_fail(e);
+    }
+    int32_t* counters = reinterpret_cast<int32_t*>(ws + c.off_cnt);
+    e = hipMemsetAsync(counters, 0, (size_t)B * vit::kBtCounters * sizeof(int32_t), st);
+    if (e != hipSuccess) return hip_fail(e);
+
+    // ---- pass 1: checkpoint rows + terminal state
+    vit::FwdArgs a{};
+    fwd_args_from_plan(plan, a);
+    a.logE = logE;
+    a.lengths = lengths;
+    a.hist = reinterpret_cast<float*>(ws + c.off_ckpt);
+    a.fmax = reinterpret_cast<float*>(ws + c.off_cnt);
+    a.last_state = reinterpret_cast<int32_t*>(ws + c.off_last);
+    a.loglik = loglik;
+    a.B = B;
+    a.T = (int)T;
+    a.hist_rows = c.nseg;
+    a.ckpt_every = (int)K;
+    a.t_begin = 0;
+    a.t_end = (int)T;
+    e = vit::launch_wave(a, f16, st);
+    if (e != hipSuccess) return hip_fail(e);
+
+    // ---- pass 2: segments, last to first
+    vit::BtArgs b{};
+    bt_args_from_plan(plan, b);
+    b.SD = SDW;
+    b.col0 = SDW - plan->S;
+    b.mcol = 0;
+    b.xcol0 = 1;
+    b.have_fmax = 1;
+    b.hist = reinterpret_cast<const float*>(ws + c.off_seg);
+    b.hist_rows = K + 1;
+    b.last_state = reinterpret_cast<const int32_t*>(ws + c.off_slast);
+    b.lengths = reinterpret_cast<const int64_t*>(ws + c.off_slen);
+    b.entry = reinterpret_cast<int32_t*>(ws + c.off_entry);
+    b.B = B;
+    b.states_stride = T;
+    b.skip_nonpositive = 1;
+    b.counters = counters;
+    b.bt_form = 0;
+    if (!vit::sparse_backtrace_applies(b)) return VIT_EUNSUPPORTED;
+    for (int64_t sgm = c.nseg - 1; sgm >= 0; --sgm) {
+        const int64_t s0 = sgm * K, e0 = s0 + K < T ? s0 + K : T;
+        vit::FwdArgs f = a;
+        f.ckpt_every = 0;
+        f.hist = reinterpret_cast<float*>(ws + c.off_seg);
+        f.hist_rows = K + 1;
+        f.loglik = nullptr;
+        f.t_begin = (int)s0;
+        f.t_end = (int)e0;
+        f.init_rows = sgm > 0 ? reinterpret_cast<const float*>(ws + c.off_ckpt) + (size_t)(sgm - 1) * SDW : nullptr;
+        f.init_stride = (int64_t)c.nseg * SDW;
+        e = vit::launch_wave(f, f16, st);
+        if (e != hipSuccess) return hip_fail(e);
+        e = vit::launch_segment_prep(lengths, B, (int)T, (int)s0, (int)e0, states, reinterpret_cast<const int32_t*>(ws + c.off_last),
+                                     reinterpret_cast<int64_t*>(ws + c.off_slen), reinterpret_cast<int32_t*>(ws + c.off_slast), st);
+        if (e != hipSuccess) return hip_fail(e);
+        b.T = (int)(e0 < T ? e0 - s0 + 1 : e0 - s0);      // the frame behind the segment is the sub-problem's terminal frame
+        b.states = states + s0;
+        b.chunks = vit::sparse_backtrace_chunks(B, b.T);
+        b.warm = vit::kBtWarmSparse;
+        e = vit::launch_backtrace_sparse(b, st);
+        if (e != hipSuccess) return hip_fail(e);
+    }
+    return VIT_OK;
 }
 
 int vit_voicing_map(const int32_t* states, int64_t n, int32_t n_bins, uint8_t* voiced, int32_t* bins,

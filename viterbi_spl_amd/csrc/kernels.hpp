@@ -61,7 +61,12 @@ struct FwdArgs {
     int wave_ok, wave_npl, wave_dk;
     int wave_flags;         // bit 0: force the 256-register (two waves per SIMD) instantiation, bit 1: the 512-register one up to 1024 songs
     int hist_half;          // wave form: 1 = only the delta rows of even frames are stored (wave.hip, HM 1)
-    int64_t hist_rows;      // history rows per song: T, or (T + 1) / 2 with hist_half
+    int64_t hist_rows;      // history rows per song: T, or (T + 1) / 2 with hist_half; checkpoint pass: segments + 1
+    // wave form, vit_decode_checkpointed: ckpt_every > 0 = pass 1 (checkpoint rows only, wave.hip HM 5); t_begin > 0 / t_end < T = a
+    // segment resumed from init_rows [B][64 * npl] (row t stored at t - t_begin)
+    int ckpt_every, t_begin, t_end;
+    const float* init_rows;
+    int64_t init_stride;    // floats from one song's init row to the next
     int win_shift;          // 0..3: delta is stored shifted by this many floats in LDS so that the window starts of a
                             // 16-lane group are 16-byte aligned in the SAME copy order (bank-conflict-free b128 reads)
 };
@@ -96,6 +101,8 @@ struct BtArgs {
     int mcol_odd, xcol0_odd;
     const void* logE;       // [B,T,S] the tensor vit_forward decoded (f32 or f16)
     int e_f16;
+    int64_t states_stride;  // states of song b start at states + b * states_stride (T; a segment of a checkpointed decode: the whole song's T)
+    int skip_nonpositive;   // sparse kernel: a song whose lengths[] entry is < 1 is skipped (segments; vit_decode clamps to 1 instead)
     int32_t* counters;      // [B][kBtCounters] per-song event counts of the sparse / half / half-wave kernels (zeroed by vit_backtrace)
 };
 
@@ -103,6 +110,10 @@ hipError_t launch_dense(const FwdArgs& a, int songs_per_group, bool f16, hipStre
 hipError_t launch_step(const FwdArgs& a, bool f16, hipStream_t st);
 hipError_t launch_banded(const FwdArgs& a, bool f16, hipStream_t st);
 hipError_t launch_wave(const FwdArgs& a, bool f16, hipStream_t st);   // wave.hip: one song per wavefront
+// per song, for the segment [s0, e0) of a checkpointed decode: the sub-problem's length (0: the song ends before s0) and the state
+// its back-trace starts from (the state already decided at frame e0, or the song's terminal state)
+hipError_t launch_segment_prep(const int64_t* lengths, int64_t B, int T, int s0, int e0, const int32_t* states, const int32_t* last,
+                               int64_t* seg_len, int32_t* seg_last, hipStream_t st);
 // history layout of the wave form: row stride 64*npl floats, state i in column 64*npl - S + i, the frame maximum in column 0,
 // a copy of delta of extra column k in column 1 + k
 constexpr int wave_hist_stride(int npl) { return 64 * npl; }

@@ -139,6 +139,13 @@ __device__ __forceinline__ void store_row(float* __restrict__ p, const float (&d
 // frame t-1 -- they are still in scalar registers when row t is stored, so the odd frames cost no store at all.  The back-trace
 // (backtrace_half.hip) rebuilds the 32 delta values of an odd frame that it needs from the stored row before it and the
 // emission row, with the very sums and maxima of this kernel's recursion: 768 instead of 1536 history bytes per frame.
+// 5: checkpoints only (vit_decode_checkpointed, pass 1): row (t + 1) / K - 1 for the frames t with (t + 1) % K == 0 -- the row
+// in front of every segment of K frames; every other frame's store goes to one scratch row per song (the same address over
+// and over: it stays in L2), so that no branch surrounds a store.
+//
+// Segments (HM 0, vit_decode_checkpointed pass 2): FwdArgs::t_begin > 0 resumes from init_rows[song] = delta_{t_begin - 1} in
+// slot order (a checkpoint row; lane 0's scalar slots are idle slots and are reset to -inf), computes frames t_begin ..
+// min(t_end, T_b) - 1 and stores row t at t - t_begin; the terminal state is pass 1's business.
 template <int NPL, int D, int NX, int PF, int WPS, int HM, typename ET>
 __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
     constexpr int H = wave_halo(NPL, D);
@@ -151,9 +158,12 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int song = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (song >= a.B) return;                   // whole waves only; there is no barrier in this kernel
-    const int Tb = song_length_of(a.lengths, song, T);
+    const int t0 = HM == 0 ? a.t_begin : 0;                                    // first frame of this launch
+    const int Tl = song_length_of(a.lengths, song, T);
+    const int Tb = HM == 0 && a.t_end < Tl ? a.t_end : Tl;                     // one past the last frame of this launch
+    if (Tb <= t0) return;                                                      // (segments: the song ended before this one)
     const ET* __restrict__ E = reinterpret_cast<const ET*>(a.logE) + (size_t)song * T * S;
-    float* __restrict__ hist = a.hist + (size_t)song * a.hist_rows * SDW;     // hist_rows = T (HM 0) or (T + 1) / 2 (HM 1)
+    float* __restrict__ hist = a.hist + (size_t)song * a.hist_rows * SDW;     // hist_rows = T (HM 0), (T + 1) / 2 (HM 1), segments + 1 (HM 5)
 
     // ---------------- per-lane constants
     const int o = SDW - S;                                 // idle leading slots (>= 1)
@@ -213,7 +223,12 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
 #pragma unroll
             for (int x = 0; x < NX; ++x) v[2 + NX + x] = lane == 0 ? xp[x] : v[2 + NX + x];
         }
-        store_row<NPL>(hist + (size_t)(HM == 1 ? t >> 1 : t) * SDW + NPL * lane, v);
+        size_t row = HM == 1 ? t >> 1 : t - t0;
+        if (HM == 5) {
+            const int q = (t + 1) / a.ckpt_every;
+            row = (t + 1) - q * a.ckpt_every == 0 && q - 1 < a.hist_rows - 1 ? q - 1 : a.hist_rows - 1;     // checkpoint, else the scratch row
+        }
+        store_row<NPL>(hist + row * SDW + NPL * lane, v);
     };
     // delta of the extra columns, wave-uniform
     auto extra_deltas = [&](const float (&d)[NPL], float (&xd)[NX > 0 ? NX : 1]) {
@@ -226,15 +241,19 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
         }
     };
 
-    // ---------------- frame 0
+    // ---------------- frame 0, or the checkpoint row in front of this segment
     float d[NPL];
-    {
+    if (t0 == 0) {
         const float* __restrict__ lpi = reinterpret_cast<const float*>(a.image + a.off_logpi);
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
             const int j = j0 + k;
             d[k] = j >= 0 ? lpi[j] + RowIO<NPL, ET>::load1(E + j) : -INFINITY;
         }
+    } else {
+        const float* __restrict__ ir = a.init_rows + (size_t)song * a.init_stride + NPL * lane;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) d[k] = j0 + k >= 0 ? ir[k] : -INFINITY;
     }
     auto frame_max = [&](const float (&v)[NPL]) -> float {
         float loc = v[0];
@@ -245,11 +264,12 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
     float M = frame_max(d);
     float xd[NX > 0 ? NX : 1] = {};
     extra_deltas(d, xd);
-    store_hist(0, d, M, xd, M, xd);
+    if (t0 == 0) store_hist(0, d, M, xd, M, xd);
+    const int t1 = t0 == 0 ? 1 : t0;           // first frame the loop computes
 
     float er[PF][NPL];
 #pragma unroll
-    for (int q = 0; q < PF; ++q) load_row(1 + q < Tb ? 1 + q : Tb - 1, er[q]);
+    for (int q = 0; q < PF; ++q) load_row(t1 + q < Tb ? t1 + q : Tb - 1, er[q]);
 #pragma unroll
     for (int k = 0; k < NPL; ++k)
 #pragma unroll
@@ -309,12 +329,12 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
         M = frame_max(d);
         extra_deltas(d, xd);               // for the next frame's candidates, and for the history row
         if (decltype(stored)::value && HM != 2 && HM != 4) store_hist(t, d, M, xd, Mp, xp);
-        if (HM < 3) load_row(t + PF < Tb ? t + PF : Tb - 1, e);     // (HM 2 / 3 / 4: timing builds only -- no stores / no loads / neither)
+        if (HM != 3 && HM != 4) load_row(t + PF < Tb ? t + PF : Tb - 1, e);     // (HM 2 / 3 / 4: timing builds only -- no stores / no loads / neither)
     };
     // The loop body is a whole number of frame pairs when only even frames are stored: t is odd at its top, frame t + q is
     // even for odd q, and "store or not" is a compile-time property of each unrolled frame (no branch around a store).
     constexpr int UN = (HM == 1 && (PF & 1)) ? 2 * PF : PF;
-    int t = 1;
+    int t = t1;
     for (; t + UN - 1 < Tb; t += UN) {
 #pragma unroll
         for (int q = 0; q < UN; ++q) {
@@ -329,8 +349,8 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
             else frame(t + q, er[q % PF], std::false_type{});
         }
 
-    // ---------------- terminal state: lowest-index argmax of delta_{Tb-1}
-    {
+    // ---------------- terminal state: lowest-index argmax of delta_{Tb-1} (not in a segment launch)
+    if (HM != 0 || a.t_end >= T) {
         float bv = -INFINITY;
         int bi = kBigI;
 #pragma unroll
@@ -383,7 +403,10 @@ static hipError_t launch_wave_x(const FwdArgs& a, hipStream_t st) {
         return hipGetLastError();
     }
 #endif
-    if (a.hist_half) {
+    if (a.ckpt_every > 0) {
+        if (one) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF1, 1, 5, ET>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 5, ET>), dim3(grid), dim3(256), 0, st, a);
+    } else if (a.hist_half) {
         if (one) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF1, 1, 1, ET>), dim3(grid), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 1, ET>), dim3(grid), dim3(256), 0, st, a);
     } else {
@@ -410,6 +433,29 @@ static hipError_t launch_wave_e(const FwdArgs& a, hipStream_t st) {
         case 6: return launch_wave_n<6, 14, ET>(a, st);
         default: return hipErrorInvalidConfiguration;
     }
+}
+
+__global__ void segment_prep_kernel(const int64_t* __restrict__ lengths, int64_t B, int T, int s0, int e0, const int32_t* __restrict__ states,
+                                    const int32_t* __restrict__ last, int64_t* __restrict__ seg_len, int32_t* __restrict__ seg_last) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int Tb = song_length_of(lengths, (int)b, T);
+    if (Tb > e0) {                    // the song goes on behind this segment: its state at frame e0 is decided already
+        seg_len[b] = e0 - s0 + 1;
+        seg_last[b] = states[(size_t)b * T + e0];
+    } else if (Tb > s0) {             // the song ends inside this segment: pass 1 left its terminal state
+        seg_len[b] = Tb - s0;
+        seg_last[b] = last[b];
+    } else {
+        seg_len[b] = 0;
+        seg_last[b] = 0;
+    }
+}
+
+hipError_t launch_segment_prep(const int64_t* lengths, int64_t B, int T, int s0, int e0, const int32_t* states, const int32_t* last,
+                               int64_t* seg_len, int32_t* seg_last, hipStream_t st) {
+    hipLaunchKernelGGL(segment_prep_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, lengths, B, T, s0, e0, states, last, seg_len, seg_last);
+    return hipGetLastError();
 }
 
 hipError_t launch_wave(const FwdArgs& a, bool f16, hipStream_t st) {

@@ -208,6 +208,41 @@ class ViterbiDecoder:
             states = states.to(out_dtype)
         return (states[0], loglik[0]) if single else (states, loglik)
 
+    # ------------------------------------------------------------------ bounded-workspace decode
+    def workspace_bytes_checkpointed(self, B: int, T: int, segment_frames: int) -> int:
+        need = int(_lib.load().vit_workspace_bytes_checkpointed(self._plan, B, T, int(segment_frames)))
+        if need == 0 and B > 0:
+            raise _lib.ViterbiHipError("checkpointed decode needs a plan with the wave form and segment_frames >= 64")
+        return need
+
+    def decode_checkpointed(self, emission_logits: torch.Tensor, segment_frames: int = 1024, lengths: Optional[torch.Tensor] = None,
+                            out_dtype: torch.dtype = torch.int64, workspace: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """``decode`` with a bounded workspace (``vit_decode_checkpointed``): about ``T / segment_frames + segment_frames`` delta
+        rows per song instead of ``T`` -- the reference keeps its work buffers for one song at a time
+        (tonet/for_paper.py:1852-1853).  Same states, same log-likelihood; about twice the forward work.  ``workspace``: an
+        optional uint8 tensor of at least ``workspace_bytes_checkpointed(...) + 256`` bytes to decode in."""
+        lib = _lib.load()
+        logE, single, dt = self._check_emissions(emission_logits)
+        B, T, _ = logE.shape
+        states = torch.empty((B, T), dtype=torch.int32, device=self.device)
+        loglik = torch.empty((B,), dtype=torch.float32, device=self.device)
+        if lengths is not None and (lengths.dtype != torch.int64 or tuple(lengths.shape) != (B,) or lengths.device != self.device):
+            raise ValueError("lengths must be an int64 [B] tensor on the decoder's device")
+        if B > 0:
+            need = self.workspace_bytes_checkpointed(B, T, segment_frames)
+            ws = workspace if workspace is not None else torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            if ws.dtype != torch.uint8 or ws.device != self.device or ws.numel() < need + 256:
+                raise ValueError(f"workspace must be a uint8 tensor of at least {need + 256} bytes on the decoder's device")
+            with torch.cuda.device(self.device):
+                rc = lib.vit_decode_checkpointed(self._plan, logE.data_ptr(), dt, B, T, lengths.data_ptr() if lengths is not None else None,
+                                                 (ws.data_ptr() + 255) & ~255, ws.numel() - 256, states.data_ptr(), loglik.data_ptr(),
+                                                 int(segment_frames), torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(rc, "vit_decode_checkpointed")
+            torch.cuda.current_stream(self.device).synchronize()      # a workspace allocated here must outlive the kernels
+        if out_dtype != torch.int32:
+            states = states.to(out_dtype)
+        return (states[0], loglik[0]) if single else (states, loglik)
+
     def voicing(self, states: torch.Tensor, n_bins: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """voiced = state < n_bins, bins = min(state, n_bins-1) (tonet/for_paper.py:1828-1829)."""
         n_bins = self.S - 1 if n_bins is None else int(n_bins)
