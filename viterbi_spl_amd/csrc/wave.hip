@@ -143,7 +143,8 @@ __device__ __forceinline__ void store_row(float* __restrict__ p, const float (&d
 // in front of every segment of K frames; every other frame's store goes to one scratch row per song (the same address over
 // and over: it stays in L2), so that no branch surrounds a store.
 //
-// Segments (HM 0, vit_decode_checkpointed pass 2): FwdArgs::t_begin > 0 resumes from init_rows[song] = delta_{t_begin - 1} in
+// 6: a segment (vit_decode_checkpointed pass 2; a mode of its own so that the t_begin arithmetic stays out of HM 0 -- folded into
+// HM 0 it cost the full-history kernel 25 %: 19.9 -> 25.1 ms at B = 1024): every row like HM 0, but FwdArgs::t_begin > 0 resumes from init_rows[song] = delta_{t_begin - 1} in
 // slot order (a checkpoint row; lane 0's scalar slots are idle slots and are reset to -inf), computes frames t_begin ..
 // min(t_end, T_b) - 1 and stores row t at t - t_begin; the terminal state is pass 1's business.
 template <int NPL, int D, int NX, int PF, int WPS, int HM, typename ET>
@@ -158,12 +159,12 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int song = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (song >= a.B) return;                   // whole waves only; there is no barrier in this kernel
-    const int t0 = HM == 0 ? a.t_begin : 0;                                    // first frame of this launch
+    const int t0 = HM == 6 ? a.t_begin : 0;                                    // first frame of this launch
     const int Tl = song_length_of(a.lengths, song, T);
-    const int Tb = HM == 0 && a.t_end < Tl ? a.t_end : Tl;                     // one past the last frame of this launch
+    const int Tb = HM == 6 && a.t_end < Tl ? a.t_end : Tl;                     // one past the last frame of this launch
     if (Tb <= t0) return;                                                      // (segments: the song ended before this one)
     const ET* __restrict__ E = reinterpret_cast<const ET*>(a.logE) + (size_t)song * T * S;
-    float* __restrict__ hist = a.hist + (size_t)song * a.hist_rows * SDW;     // hist_rows = T (HM 0), (T + 1) / 2 (HM 1), segments + 1 (HM 5)
+    float* __restrict__ hist = a.hist + (size_t)song * a.hist_rows * SDW;     // hist_rows = T (HM 0), (T + 1) / 2 (HM 1), segments (HM 5), K + 1 (HM 6)
 
     // ---------------- per-lane constants
     const int o = SDW - S;                                 // idle leading slots (>= 1)
@@ -350,7 +351,7 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
         }
 
     // ---------------- terminal state: lowest-index argmax of delta_{Tb-1} (not in a segment launch)
-    if (HM != 0 || a.t_end >= T) {
+    if (HM != 6 || a.t_end >= T) {
         float bv = -INFINITY;
         int bi = kBigI;
 #pragma unroll
@@ -406,6 +407,9 @@ static hipError_t launch_wave_x(const FwdArgs& a, hipStream_t st) {
     if (a.ckpt_every > 0) {
         if (one) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF1, 1, 5, ET>), dim3(grid), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 5, ET>), dim3(grid), dim3(256), 0, st, a);
+    } else if (a.t_begin > 0 || a.t_end < a.T) {
+        if (one) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF1, 1, 6, ET>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 6, ET>), dim3(grid), dim3(256), 0, st, a);
     } else if (a.hist_half) {
         if (one) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF1, 1, 1, ET>), dim3(grid), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 1, ET>), dim3(grid), dim3(256), 0, st, a);
