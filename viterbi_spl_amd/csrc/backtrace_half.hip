@@ -120,6 +120,7 @@ __global__ void __launch_bounds__(1024) half_backtrace_kernel(BtArgs a) {
     const int aux_even = lane == CB ? a.mcol : a.xcol0 + ((lane - W) & (kMaxExtras - 1));
     const int aux_odd = lane == CB ? a.mcol_odd : a.xcol0_odd + ((lane - W) & (kMaxExtras - 1));
     const int tb = lane < WX1 ? lane : WX1 - 1;
+    const unsigned long long cand_or_bound = (nx >= 64 - W ? ~0ull : ((1ull << (W + nx)) - 1ull)) | (1ull << CB);
     const int il = lane & 31, hh = lane >> 5;          // odd frames: source il of the window, half hh of ITS window
     bool inS[EPL], xcol[EPL];
 #pragma unroll
@@ -201,18 +202,35 @@ __global__ void __launch_bounds__(1024) half_backtrace_kernel(BtArgs a) {
             int fstop = -1;           // MODE 1: frame at which the new path met the stored one
             int fnext = first - 1;    // where the next tile starts (a miss or a rebuilt row ends this one early)
             int fdone = first;        // lowest frame decided in this pass
+            // Window starts this tile serves, as ONE interval [lo_a, lo_a + lo_span] (the odd-frame conditions: the sources of the 32
+            // windows inside the delta span, the 32 sources inside the emission span; they imply the even-frame condition).  With
+            // g = the state of span column 0:  lo_of(lo) >= g,  lo_of(lo + W - 1) + W <= g + ND,  ce0 <= lo <= ce0 + NE - W.
+            const int g = c0 - a.col0;
+            int lo_a = ce0 > g ? ce0 : g, lo_b = ce0 + kHbNE - W < g + kHbND - W ? ce0 + kHbNE - W : g + kHbND - W;
+            if (g > 0) lo_a = lo_a > g + lo_off ? lo_a : g + lo_off;
+            if (g + kHbND - W < lo_max) lo_b = lo_b < g + kHbND - 2 * W + 1 + lo_off ? lo_b : g + kHbND - 2 * W + 1 + lo_off;
+            const unsigned lo_span = (unsigned)(lo_b - lo_a);
+            // The scalar unit of a CU serves its sixteen waves and was ~70 % busy with this loop's index arithmetic (96 scalar
+            // instructions per frame, profiles/r03_pmc_B1024_half.txt): the path state goes through an opaque VGPR copy, so that the
+            // window start, the fit check and every LDS index are vector instructions (four pipes per CU) instead.
+            const int lane_mg = lane - g;                                   // span column of window candidate `lane`, relative to lo
             for (int f = __builtin_amdgcn_readfirstlane(top); f >= first; --f) {
                 cur = __builtin_amdgcn_readfirstlane(cur);
-                const int lo = lo_of(cur);
+                int curv;
+                asm volatile("v_mov_b32 %0, %1" : "=v"(curv) : "s"(cur));
+                int lov = curv - lo_off;
+                lov = lov < 0 ? 0 : (lov > lo_max ? lo_max : lov);
+                if (__ballot((unsigned)(lov - lo_a) > lo_span)) { fnext = f; fdone = f + 1; ++n_miss; break; }
                 const int rr = (f >> 1) - r_lo;                            // tile row: frame f (even) or f - 1 (odd)
+                const int rowd = rr * kHbND, rowa = rr * kHbAux;
                 float dv;
                 if (f & 1) {
                     // ---- odd frame: rebuild delta_f[lo .. lo + W) from row f - 1 and the emission row
-                    const int s_lo = a.col0 + lo_of(lo) - c0, s_hi = a.col0 + lo_of(lo + W - 1) + W - c0;
-                    if (s_lo < 0 || s_hi > kHbND || lo < ce0 || lo + W > ce0 + kHbNE) { fnext = f; fdone = f + 1; ++n_miss; break; }
-                    const int i = lo + il;
-                    const float* __restrict__ src = td + rr * kHbND + (a.col0 + lo_of(i) - c0) + 16 * hh;
-                    const float* __restrict__ wt = tabX + i * WX1;
+                    const int iv = lov + il;                               // the source this lane rebuilds (both halves of the wave)
+                    int li = iv - lo_off;
+                    li = li < 0 ? 0 : (li > lo_max ? lo_max : li);         // start of ITS window
+                    const float* __restrict__ src = td + (rowd - g + 16 * hh) + li;
+                    const float* __restrict__ wt = tabX + iv * WX1;
                     float acc0 = -INFINITY, acc1 = -INFINITY;
 #pragma unroll
                     for (int q = 0; q < 16; q += 2) {
@@ -220,30 +238,29 @@ __global__ void __launch_bounds__(1024) half_backtrace_kernel(BtArgs a) {
                         acc1 = fmaxf(acc1, src[q + 1] + wt[16 * hh + q + 1]);
                     }
                     float acc = hb_other_half(fmaxf(acc0, acc1));
-                    const float* __restrict__ ar = ta + rr * kHbAux;
+                    const float* __restrict__ ar = ta + rowa;
                     acc = fmaxf(acc, ar[a.mcol] + wt[CB]);
                     for (int k = 0; k < nx; ++k) acc = fmaxf(acc, ar[a.xcol0 + k] + wt[W + k]);
-                    const float dw = acc + te[rr * kHbNE + (i - ce0)];
-                    dv = isw ? dw : ta[(rr + 1) * kHbAux + aux_odd];
+                    const float dw = acc + te[rr * kHbNE - ce0 + iv];
+                    dv = isw ? dw : ta[rowa + kHbAux + aux_odd];
                 } else {
-                    const int wlo = a.col0 + lo - c0;
-                    if (wlo < 0 || wlo + W > kHbND) { fnext = f; fdone = f + 1; ++n_miss; break; }
-                    dv = isw ? td[rr * kHbND + wlo + lane] : ta[rr * kHbAux + aux_even];
+                    dv = (isw ? td + rowd + lov + lane_mg : ta + rowa + aux_even)[0];
                 }
-                const float av = tabX[cur * WX1 + tb];
+                const float av = tabX[curv * WX1 + tb];
                 float v = dv + av;
-                const float mf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), CB));    // fl(M_f + c_cur)
-                const float cj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(av), CB));
-                v = cand ? v : -INFINITY;
-                const float m = hb_wave_max(v);
-                auto lowest_candidate = [&](const float mm) -> unsigned {
+                const float vc = cand ? v : -INFINITY;
+                const float m = hb_wave_max(vc);
+                // one compare: a candidate lane with v >= m attains the maximum; the bound lane with fl(M_f + c_cur) >= m means a
+                // row-constant candidate may tie or win
+                const unsigned long long ge = __ballot(v >= m) & cand_or_bound;
+                const int lo = __builtin_amdgcn_readfirstlane(lov);
+                auto lowest_candidate = [&](const unsigned long long mk) -> unsigned {
                     unsigned best = 0x7fffffffu;
-                    const unsigned long long mk = __ballot(v == mm && cand);
-                    const unsigned long long mw = mk & 0xffffffffull;
-                    if (mw) best = lo + __builtin_ctzll(mw);                   // window candidates ascend with the source index
-                    unsigned long long mx = mk & ~0xffffffffull;               // extra columns: arbitrary indices
+                    const unsigned mw = (unsigned)mk;
+                    if (mw) best = lo + __builtin_ctz(mw);                     // window candidates ascend with the source index
+                    unsigned mx = (unsigned)(mk >> 32) & ((1u << kMaxExtras) - 1u);   // extra columns: arbitrary indices
                     while (mx) {
-                        const unsigned c = __builtin_amdgcn_readlane(xs, __builtin_ctzll(mx));
+                        const unsigned c = __builtin_amdgcn_readlane(xs, 32 + __builtin_ctz(mx));
                         best = c < best ? c : best;
                         mx &= mx - 1;
                     }
@@ -251,10 +268,11 @@ __global__ void __launch_bounds__(1024) half_backtrace_kernel(BtArgs a) {
                 };
                 unsigned idx = 0x7fffffffu;
                 bool rebuilt = false;
-                if (mf < m) {
-                    idx = lowest_candidate(m);
+                if (!((ge >> CB) & 1ull)) {
+                    idx = lowest_candidate(ge);
                 } else {
                     ++n_full;
+                    const float cj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(av), CB));
                     // ---- full evaluation: every source outside the window / extra columns contributes fl(delta_f[i] + c_cur)
                     float d[EPL];
                     const float* __restrict__ grow = hist + (size_t)(f >> 1) * SD + a.col0;     // row f (even) or f - 1 (odd)
@@ -264,7 +282,7 @@ __global__ void __launch_bounds__(1024) half_backtrace_kernel(BtArgs a) {
                         // rebuild the whole of delta_f: stage delta_{f-1} in the tile's span area (the tile is dropped afterwards)
 #pragma unroll
                         for (int e = 0; e < EPL; ++e) td[e * 64 + lane] = d[e];
-                        const float* __restrict__ ar = ta + rr * kHbAux;
+                        const float* __restrict__ ar = ta + rowa;
                         const float Mp = ar[a.mcol];
 #pragma unroll
                         for (int e = 0; e < EPL; ++e) {
@@ -296,7 +314,7 @@ __global__ void __launch_bounds__(1024) half_backtrace_kernel(BtArgs a) {
                         const unsigned long long mk = __ballot(vf[e] == mm && inS[e]);
                         if (mk) { const unsigned c = e * 64 + __builtin_ctzll(mk); idx = c < idx ? c : idx; }
                     }
-                    const unsigned c = lowest_candidate(mm);
+                    const unsigned c = lowest_candidate(__ballot(vc == mm && cand));
                     idx = c < idx ? c : idx;
                     if (idx == 0x7fffffffu) idx = 0;        // an all -inf frame resolves to index 0 like np.argmax
                 }

@@ -390,10 +390,10 @@ hipError_t launch_backtrace_sparse(const BtArgs& a, hipStream_t st, int phases) 
 
 // more, shorter chunks than the whole-row kernels: the sparse kernel hides its fetch latency with waves, not with a
 // second tile in registers (sixteen waves per CU at 1024 songs and up)
-int sparse_backtrace_chunks(int64_t B, int T) {
+int sparse_backtrace_chunks(int64_t B, int T, int n_cus) {
     // (song, chunk) waves up to the resident capacity of the chip (sixteen per CU), never beyond: one wave more starts a second round
     // and doubles the kernel's time (B = 320: thirteen chunks 2.1 ms, twelve 1.2 ms)
-    long long c = (4 * 1024) / (B > 0 ? B : 1);
+    long long c = (16ll * (n_cus > 0 ? n_cus : 256)) / (B > 0 ? B : 1);      // sixteen waves per CU
     const long long cmax = T / (8 * kBtWarmSparse) > 1 ? T / (8 * kBtWarmSparse) : 1;
     c = c > cmax ? cmax : c;
     c = c > kBtMaxChunks ? kBtMaxChunks : c;

@@ -51,6 +51,7 @@ struct vit_plan {
     vit::ImageLayout L;
     std::vector<uint8_t> host_image;
     const uint8_t* dev_image = nullptr;
+    int n_cus = 256;           // compute units of the device the image was uploaded to (vit_plan_upload): kernel-selection thresholds scale with it
     Tuning tune;
     mutable std::mutex mu;
     mutable std::vector<FwdStamp> stamps;   // most recent first, at most kMaxStamps
@@ -69,9 +70,10 @@ inline int hist_stride_ws(const vit_plan* p) {
     return sd > sw ? sd : sw;
 }
 constexpr size_t kMaxStamps = 64;    // workspaces with a forward pass on record per plan (include/viterbi_hip.h, vit_forward)
-constexpr int kWaveMinBatch = 513;   // from here on one song per wavefront beats one song per workgroup: two workgroups per CU hold 512
-                                     // songs (B = 512: 18.8 vs 14.2 ms forward); the 513th starts a second round (B = 576: 18.8 vs
-                                     // 19.8 ms, B = 1024: 20.0 vs 25-27 ms)
+// From two workgroups per CU + 1 songs on, one song per wavefront beats one song per workgroup (256 CUs: two workgroups per CU hold 512
+// songs, B = 512: 18.8 vs 14.2 ms forward; the 513th starts a second round, B = 576: 18.8 vs 19.8 ms, B = 1024: 20.0 vs 25-27 ms;
+// DESIGN.md 6).
+inline int64_t wave_min_batch(const vit_plan* p) { return 2 * (int64_t)p->n_cus + 1; }
 
 void stamp_erase(const vit_plan* p, const void* ws) {
     std::lock_guard<std::mutex> g(p->mu);
@@ -219,6 +221,9 @@ int vit_plan_upload(vit_plan* plan, void* device_image, size_t bytes, vit_stream
                                   (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e);
     plan->dev_image = static_cast<const uint8_t*>(device_image);
+    int dev = 0, cus = 0;      // the thresholds below are "how many workgroups / waves fit the chip at once": from the device, not from "256"
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+        plan->n_cus = cus;
     return VIT_OK;
 }
 
@@ -261,7 +266,7 @@ static int resolve_family(const vit_plan* plan, int algo, int64_t B) {
                                           (plan->bp.floor_ok && plan->S < nwt * 64 && vit::floor_form_instantiated(plan->bp.W, nwt)));
     const bool wave_ok = plan->bp.ok && plan->bp.wave_ok;
     const int ff = plan->tune.forward_form;
-    const int64_t wmin = plan->tune.wave_min_batch > 0 ? plan->tune.wave_min_batch : kWaveMinBatch;
+    const int64_t wmin = plan->tune.wave_min_batch > 0 ? plan->tune.wave_min_batch : wave_min_batch(plan);
     if (algo == VIT_ALGO_DENSE) return 1;
     if (algo == VIT_ALGO_WAVE) return wave_ok ? 3 : VIT_EUNSUPPORTED;
     if (algo == VIT_ALGO_GROUP) return group_ok ? 2 : VIT_EUNSUPPORTED;
@@ -473,7 +478,7 @@ int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* len
         b.e_f16 = st.e_f16;
     }
     if (st.half) {
-        b.chunks = vit::sparse_backtrace_chunks(B, (int)T);
+        b.chunks = vit::sparse_backtrace_chunks(B, (int)T, plan->n_cus);
         b.warm = vit::kBtWarmSparse;
         if (tn.bt_chunks >= 1 && tn.bt_chunks <= vit::kBtMaxChunks) b.chunks = tn.bt_chunks;
         if (tn.bt_warm >= 0) b.warm = tn.bt_warm;
@@ -481,7 +486,7 @@ int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* len
         return eh == hipSuccess ? VIT_OK : hip_fail(eh);
     }
     const bool sparse = b.bt_form == 0 && vit::sparse_backtrace_applies(b);
-    b.chunks = sparse ? vit::sparse_backtrace_chunks(B, (int)T) : vit::backtrace_chunks(B, (int)T);
+    b.chunks = sparse ? vit::sparse_backtrace_chunks(B, (int)T, plan->n_cus) : vit::backtrace_chunks(B, (int)T);
     b.warm = sparse ? vit::kBtWarmSparse : vit::kBtWarm;
     // test hooks (vit_plan_set_option): force the chunking / warm-up so that the verify-and-repair pass is exercised
     if (tn.bt_chunks >= 1 && tn.bt_chunks <= vit::kBtMaxChunks) b.chunks = tn.bt_chunks;
@@ -627,7 +632,7 @@ int vit_decode_checkpointed(const vit_plan* plan, const void* logE, int emis_dty
         if (e != hipSuccess) return hip_fail(e);
         b.T = (int)(e0 < T ? e0 - s0 + 1 : e0 - s0);      // the frame behind the segment is the sub-problem's terminal frame
         b.states = states + s0;
-        b.chunks = vit::sparse_backtrace_chunks(B, b.T);
+        b.chunks = vit::sparse_backtrace_chunks(B, b.T, plan->n_cus);
         b.warm = vit::kBtWarmSparse;
         e = vit::launch_backtrace_sparse(b, st);
         if (e != hipSuccess) return hip_fail(e);

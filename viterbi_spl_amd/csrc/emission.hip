@@ -207,7 +207,12 @@ static hipError_t launch_obs(const float* logits, int64_t n_frames, int U, int s
     if (n_frames <= 0) return hipSuccess;
     if (spw < 1 || spw >= U || spw > 64 || U > 768) return hipErrorInvalidValue;
     int64_t blocks = (n_frames + kObsWaves - 1) / kObsWaves;
-    if (blocks > 256 * 6) blocks = 256 * 6;       // six workgroups of four frames' LDS fit a CU: one resident wave per frame slot, no second round
+    static int n_cus = 0;                         // (no plan at this entry point: ask the device once)
+    if (n_cus == 0) {
+        int dev = 0, cus = 0;
+        n_cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? cus : 256;
+    }
+    if (blocks > (int64_t)n_cus * 6) blocks = (int64_t)n_cus * 6;   // six workgroups of four frames' LDS fit a CU: one resident wave per frame slot, no second round
     const size_t lds = sizeof(float) * kObsWaves * 4 * (U + 2 * spw + 1);
     if (U <= 384)
         hipLaunchKernelGGL((observation_kernel<6, MODE>), dim3((int)blocks), dim3(kObsWaves * 64), lds, st, logits, n_frames, U,

@@ -125,7 +125,7 @@ hipError_t launch_backtrace_sparse(const BtArgs& a, hipStream_t st, int phases =
 // backtrace_half.hip: the same for a half history (wave form, even rows only): odd frames are rebuilt from the row before them
 bool half_backtrace_applies(const BtArgs& a);
 hipError_t launch_backtrace_half(const BtArgs& a, hipStream_t st, int phases = 3);
-int sparse_backtrace_chunks(int64_t B, int T);
+int sparse_backtrace_chunks(int64_t B, int T, int n_cus);
 hipError_t launch_voicing_map(const int32_t* states, int64_t n, int32_t n_bins, uint8_t* voiced, int32_t* bins,
                               hipStream_t st);
 hipError_t launch_scan_selftest(const float* vals, int n_waves, int mode, float* out_v, int32_t* out_i,
