@@ -402,11 +402,9 @@ def extra_blocks(dev, args):
         r = sweep_row(dec, A, pi, E, "auto", NS, overlapped=False)
         if dec.info["banded_ok"]:
             r["valu_ceiling"] = valu_ceiling(dec, 722, 256 * T, r["forward_ms"])
-        else:   # the step-structured kernel: 2 x 9 band windows of 20 sources + the far maximum per target
-            cand = 2 * 9 * 20 + 2
-            peak = VALU_LANE_RATE / (722 * cand)
-            r["valu_ceiling"] = {"candidates_per_state": cand, "lane_instructions_per_frame": 722 * cand, "peak_Mframes_per_s": peak / 1e6,
-                                 "achieved_Mframes_per_s": 256 * T / (r["forward_ms"] * 1e-3) / 1e6, "frac": 256 * T / (r["forward_ms"] * 1e-3) / peak}
+        else:   # the step-structured kernel shares its band maxima between targets: there is no per-candidate instruction floor to quote
+            r["valu_ceiling"] = None
+            r["valu_ceiling_note"] = "not defined for the step-structured kernel (band maxima are shared between the four targets of a lane; DESIGN.md 4.2b)"
         c4[name] = r
         del E, dec
         torch.cuda.empty_cache()

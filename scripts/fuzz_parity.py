@@ -1,6 +1,6 @@
 """Randomised parity run (test infrastructure; run on the GPU box): random state counts, band half-widths, matrix families,
-batch shapes, ragged lengths, emission kinds and storage types; every kernel family the plan allows and both back-trace forms
-against the C restatement in oracle/.  argv: seconds to run (default 240), seed (default 1)."""
+batch shapes, ragged lengths, emission kinds and storage types; every kernel family the plan allows and both back-trace forms, the wave
+form's half history and the checkpointed decode against the C restatement in oracle/.  argv: seconds to run (default 240), seed (default 1)."""
 import os
 import sys
 import time
@@ -73,7 +73,7 @@ while time.time() - t0 < budget:
         if dec.info["banded_ok"]:
             forms += [("group", 0), ("group", 2)]
             if dec.info["wave_ok"]:
-                forms += [("wave", 0), ("wave", 2)]
+                forms += [("wave", 0), ("wave", 2), ("wave-half", 0), ("checkpointed", 0)]
         if S <= 400 or rng.random() < 0.3:
             forms += [("dense", 0)]
         chunks = int(rng.choice([0, 0, 2, 7, 32]))
@@ -85,7 +85,13 @@ while time.time() - t0 < budget:
                 dec.set_option("bt_chunks", chunks)
                 dec.set_option("bt_warm", warm)
             try:
-                st, ll = dec.decode(E, lengths=lens, algo=algo, out_dtype=torch.int32)
+                if algo == "wave-half":          # even delta rows only; refused (loudly) where the plan does not allow it
+                    dec.set_option("wave_history", 2)
+                    st, ll = dec.decode(E, lengths=lens, algo="wave", out_dtype=torch.int32)
+                elif algo == "checkpointed":
+                    st, ll = dec.decode_checkpointed(E, segment_frames=int(rng.choice([64, 65, 100, 256, 2048])), lengths=lens, out_dtype=torch.int32)
+                else:
+                    st, ll = dec.decode(E, lengths=lens, algo=algo, out_dtype=torch.int32)
             except Exception as e:   # noqa: BLE001  a forced family may be refused (loudly); "auto" must always decode
                 dec.set_option("reset", 0)
                 print("refused" if algo != "auto" else "FAIL", name, {k: dec.info[k] for k in ("banded_ok", "wave_ok", "group_window", "n_extras", "n_dense_rows")}, B, T, algo, btf, e, flush=True)
