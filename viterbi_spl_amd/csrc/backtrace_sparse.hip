@@ -117,6 +117,7 @@ __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
         wmask[k] = nwin >= 64 ? ~0ull : (nwin <= 0 ? 0ull : ((1ull << nwin) - 1ull));
     }
     const int kb = CB >> 6, lb = CB & 63;                                  // slot / lane of the bound candidate
+    const unsigned long long cand_or_bound = (W + nx >= 64 ? ~0ull : ((1ull << (W + nx)) - 1ull)) | (1ull << (CB & 63));   // (KC == 1)
     // aux loads: entry e of row r by lane r * 8 + e (two halves of eight rows)
     const int aux_e = lane & 7;
     const int aux_col = aux_e == 0 ? a.mcol : (aux_e <= nx ? (a.xcol0 >= 0 ? a.xcol0 + aux_e - 1 : a.col0 + a.extras[(aux_e - 1) & (kMaxExtras - 1)]) : a.mcol);
@@ -180,39 +181,63 @@ __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
             int rmiss = -1;          // row whose window left the span: the tile is re-fetched from there
             for (int r = __builtin_amdgcn_readfirstlane(rows - 1); r >= 0; --r) {
                 cur = __builtin_amdgcn_readfirstlane(cur);
+                constexpr bool kLean = AFF && KC == 1 && !GT;          // the reference's S = 321 / 361 matrices
                 int lo;
-                if (AFF) { lo = cur - a.lo_off; lo = lo < 0 ? 0 : (lo > lo_max ? lo_max : lo); }
-                else lo = __builtin_amdgcn_readfirstlane(loL[cur]);
-                const int wlo = a.col0 + lo - c0;                       // window start inside the span
-                if (wlo < 0 || wlo + W > kSpNS) { rmiss = r; ++n_miss; break; }
-                const float* trow = tile + r * kSpRS;
                 float v[KC], av[KC];
+                float m;
+                bool fail;                                             // a row-constant candidate may tie or win: full evaluation
+                unsigned long long ge = 0;                             // kLean: candidate lanes that attain the maximum
+                if constexpr (kLean) {
+                    // The scalar unit of a CU serves its sixteen waves and was ~60 % busy here (42 scalar instructions per frame,
+                    // profiles/r03_pmc_B2048_full.txt): the path state goes through an opaque VGPR copy so that the window start,
+                    // the fit check and the LDS indices are vector instructions, and ONE compare yields both the matching
+                    // candidates and the bound: lane CB holds fl(M_t + c_cur), and fl(M_t + c_cur) >= max <=> not (mf < max).
+                    int curv;
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(curv) : "s"(cur));
+                    int lov = curv - a.lo_off;
+                    lov = lov < 0 ? 0 : (lov > lo_max ? lo_max : lov);
+                    const int wlov = lov + (a.col0 - c0);              // window start inside the span
+                    if (__ballot((unsigned)wlov > (unsigned)(kSpNS - W))) { rmiss = r; ++n_miss; break; }
+                    const float* trow = tile + r * kSpRS;
+                    const float dv = trow[isw[0] ? wlov + lane : kSpNS + auxi[0]];
+                    av[0] = tabX[curv * WX1 + tb[0]];
+                    const float vv = dv + av[0];
+                    v[0] = cand[0] ? vv : -INFINITY;
+                    m = sp_wave_max(v[0]);
+                    ge = __ballot(vv >= m) & cand_or_bound;
+                    fail = (ge >> CB) & 1ull;
+                    lo = __builtin_amdgcn_readfirstlane(lov);
+                } else {
+                    if (AFF) { lo = cur - a.lo_off; lo = lo < 0 ? 0 : (lo > lo_max ? lo_max : lo); }
+                    else lo = __builtin_amdgcn_readfirstlane(loL[cur]);
+                    const int wlo = a.col0 + lo - c0;                       // window start inside the span
+                    if (wlo < 0 || wlo + W > kSpNS) { rmiss = r; ++n_miss; break; }
+                    const float* trow = tile + r * kSpRS;
 #pragma unroll
-                for (int k = 0; k < KC; ++k) {
-                    const float dv = trow[isw[k] ? wlo + 64 * k + lane : kSpNS + auxi[k]];
-                    av[k] = GT ? gtab[(size_t)cur * WX1 + tb[k]] : tabX[cur * WX1 + tb[k]];
-                    v[k] = dv + av[k];
-                }
-                float mf = 0.f, cj = 0.f;                              // fl(M_t + c_cur) and c_cur, from the bound candidate
-#pragma unroll
-                for (int k = 0; k < KC; ++k)
-                    if (KC == 1 || k == kb) {
-                        mf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), lb));
-                        cj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(av[k]), lb));
+                    for (int k = 0; k < KC; ++k) {
+                        const float dv = trow[isw[k] ? wlo + 64 * k + lane : kSpNS + auxi[k]];
+                        av[k] = GT ? gtab[(size_t)cur * WX1 + tb[k]] : tabX[cur * WX1 + tb[k]];
+                        v[k] = dv + av[k];
                     }
-                float mloc = -INFINITY;
+                    float mf = 0.f;                                         // fl(M_t + c_cur), from the bound candidate
 #pragma unroll
-                for (int k = 0; k < KC; ++k) {
-                    v[k] = cand[k] ? v[k] : -INFINITY;
-                    mloc = fmaxf(mloc, v[k]);
+                    for (int k = 0; k < KC; ++k)
+                        if (KC == 1 || k == kb) mf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), lb));
+                    float mloc = -INFINITY;
+#pragma unroll
+                    for (int k = 0; k < KC; ++k) {
+                        v[k] = cand[k] ? v[k] : -INFINITY;
+                        mloc = fmaxf(mloc, v[k]);
+                    }
+                    m = sp_wave_max(mloc);
+                    fail = !(mf < m);
                 }
-                const float m = sp_wave_max(mloc);
                 auto lowest_candidate = [&](const float mm) -> unsigned {
                     unsigned best = 0x7fffffffu;
                     bool have_w = false;
 #pragma unroll
                     for (int k = 0; k < KC; ++k) {
-                        const unsigned long long mk = __ballot(v[k] == mm && cand[k]);
+                        const unsigned long long mk = (kLean && mm == m) ? (ge & ~(1ull << CB)) : __ballot(v[k] == mm && cand[k]);
                         const unsigned long long mw = mk & wmask[k];
                         if (mw && !have_w) {                                 // window candidates ascend with the source index
                             const unsigned c = lo + 64 * k + __builtin_ctzll(mw);
@@ -229,9 +254,13 @@ __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
                     return best;
                 };
                 unsigned idx = 0x7fffffffu;
-                if (mf < m) {
+                if (!fail) {
                     idx = lowest_candidate(m);
                 } else {
+                    float cj = 0.f;                                         // c_cur, from the bound candidate's table entry
+#pragma unroll
+                    for (int k = 0; k < KC; ++k)
+                        if (KC == 1 || k == kb) cj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(av[k]), lb));
                     ++n_full;
                     // ---- full evaluation, straight from the history row in global memory: every source outside the
                     //      window / extra columns contributes fl(delta_t[i] + c_cur)
