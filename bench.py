@@ -346,7 +346,7 @@ def extra_blocks(dev, args):
     logA_T, log_pi = make_params("tonet", 361, 14)
     dec = ViterbiDecoder(logA_T, log_pi, dev)
     sweep = {}
-    for B in (256, 512, 1024, 2048):
+    for B in (1, 256, 512, 1024, 2048):       # B = 1 is BASELINE configs[1]: a single song, one workgroup, delta resident in LDS
         E = tiled_emissions(synth.emissions_peaks, B, T, 361, 1234, dev, torch.float32)
         sweep[f"B{B}"] = sweep_row(dec, logA_T, log_pi, E, "banded", NS)
         if B >= 1024:           # the wave form with the delta rows of even frames only (vit_plan_set_option "wave_history" = 2)
