@@ -313,6 +313,17 @@ def sweep_row(dec, logA_T, log_pi, E, algo, steps, lengths=None, overlapped=True
     vc = valu_ceiling(dec, S, frames, r["forward_ms"])
     if vc:
         r["forward_valu_frac"] = vc["frac"]
+    if lengths is None and S == 361 and esz == 4:      # HBM bytes of the same kernels and shapes from the committed PMC passes (looked up)
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(f"sweep_{r['forward_kernel']}_B{B}_{r['history']}")
+            if rec:
+                fa, wa = frames * (S * esz + S * 2), frames * (S * esz + S * 2 + 6)
+                r["traffic"] = {"forward_hbm_bytes_per_launch": rec["forward_hbm_bytes_per_launch"], "backtrace_hbm_bytes_per_launch": rec["backtrace_hbm_bytes_per_launch"],
+                                "forward_over_algorithmic": rec["forward_hbm_bytes_per_launch"] / fa,
+                                "whole_path_over_algorithmic": (rec["forward_hbm_bytes_per_launch"] + rec["backtrace_hbm_bytes_per_launch"]) / wa,
+                                "source": rec["profile"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernels and shapes; looked up, not measured in this run)"}
+        except Exception:
+            pass
     sub = [0, min(B, 32) // 2, min(B, 32) - 1]
     rs, rl = __import__("oracle.viterbi_oracle", fromlist=["x"]).decode_c(
         logA_T, log_pi, E[sub].float().cpu().numpy(), lengths=None if lengths is None else lengths[sub].cpu().numpy())
