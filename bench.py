@@ -313,7 +313,7 @@ def sweep_row(dec, logA_T, log_pi, E, algo, steps, lengths=None, overlapped=True
     vc = valu_ceiling(dec, S, frames, r["forward_ms"])
     if vc:
         r["forward_valu_frac"] = vc["frac"]
-    if lengths is None and S == 361 and esz == 4:      # HBM bytes of the same kernels and shapes from the committed PMC passes (looked up)
+    if overlapped and lengths is None and S == 361 and esz == 4:      # (the peak-sparse main rows) HBM bytes of the same kernels and shapes from the committed PMC passes (looked up)
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(f"sweep_{r['forward_kernel']}_B{B}_{r['history']}")
             if rec:
