@@ -187,10 +187,12 @@ class _PreparedViterbi:
     def __call__(self, logits):
         """``viterbi(logits) -> (voiced bool[T], bins int64[T])`` as NumPy arrays, the reference's call surface
         (tonet/for_paper.py:1817-1831, :2309).  The observation probabilities are built on the GPU (``vit_obs_*``: peak
-        picking, voicing decision and structural zeros exact; exp / log / sums within a few ulp of NumPy's, see
-        tests/test_gpu_parity.py::test_default_postprocessor_path_agreement for the measured path agreement).  Callers
-        that need the reference's bits end to end build the probabilities themselves and call
-        :meth:`viterbi_librosa_fn`, which is exact."""
+        picking, voicing decision and structural zeros exact; exp / log / sums within a few ulp of NumPy's).  Measured
+        against the host-exact pipeline (tests/test_gpu_parity.py::test_postprocessor_agreement_at_full_length): T = 30000,
+        five seeds per builder ("shaun", softmax, scaled likelihoods) -- 100 % of the frames of all fifteen songs decode to
+        the reference's states; the test's bar is 99.9 % per song with every differing frame on a path whose exact score
+        ties the reference's to 1e-6.  Callers that need the reference's bits by construction build the probabilities
+        themselves and call :meth:`viterbi_librosa_fn`, which is bit-exact."""
         voiced, bins = self.decode_logits(logits)
         return voiced.cpu().numpy(), bins.cpu().numpy().astype(np.int64)
 
