@@ -29,6 +29,8 @@ struct Tuning {
     int wave_min_batch = 0;    // batch size from which banded plans take the wave form (0 = default)
     int wave_two = 0;          // wave kernel: 1 always the 256-register instantiation (the default but for two extra columns) | 2 the 512-register
                                // one up to 1024 songs
+    int wave_uniform = 0;      // wave form: 0 = the last-state / uniform-lane variants where the plan proves them (wave.hip UV) | 1 = neither |
+                               // 2 = the last-state variant only
     int wave_history = 0;      // wave form: 0 / 1 every delta row | 2 the rows of even frames only (VIT_EUNSUPPORTED where the plan does not allow it)
     int timing = 0;
 };
@@ -51,6 +53,7 @@ struct vit_plan {
     vit::ImageLayout L;
     std::vector<uint8_t> host_image;
     const uint8_t* dev_image = nullptr;
+    int wave_u5 = 0;           // the wave kernel's uniform-lane form applies (wave.hip U5)
     int n_cus = 256;           // compute units of the device the image was uploaded to (vit_plan_upload): kernel-selection thresholds scale with it
     Tuning tune;
     mutable std::mutex mu;
@@ -183,6 +186,27 @@ int vit_plan_create(const float* logA_T, const float* log_pi, int64_t S, vit_pla
         p->L = vit::make_layout((int)S, p->bp);
         p->host_image.resize(p->L.bytes);
         vit::fill_image(logA_T, log_pi, p->bp, p->L, p->host_image.data());
+        // wave form, uniform-lane variant: six states per lane, ONE extra column = the last state, and for every lane the row constant
+        // and the extra-column weight of its slots 0..4 agree bit for bit (idle slots count as -inf)
+        if (p->bp.ok && p->bp.wave_ok && p->bp.n_extras == 1 && p->bp.extras[0] == (int)S - 1) p->wave_u5 = 1;     // (the extra column is the last state)
+        if (p->wave_u5 == 1 && p->bp.wave_npl == 6) {
+            const float* xa = reinterpret_cast<const float*>(p->host_image.data() + p->L.off_extraA);
+            const int o = 384 - (int)S;
+            bool ok = true;
+            for (int l = 0; l < 64 && ok; ++l) {
+                uint32_t c_ref = 0, x_ref = 0;
+                for (int k = 0; k < 5 && ok; ++k) {
+                    const int j = 6 * l + k - o;
+                    const float cv = j >= 0 ? p->bp.rowc[j] : -INFINITY, xv = j >= 0 ? xa[j] : -INFINITY;
+                    uint32_t cb, xb;
+                    std::memcpy(&cb, &cv, 4);
+                    std::memcpy(&xb, &xv, 4);
+                    if (k == 0) { c_ref = cb; x_ref = xb; }
+                    ok = cb == c_ref && xb == x_ref;
+                }
+            }
+            if (ok) p->wave_u5 = 2;
+        }
     } catch (const std::bad_alloc&) {
         delete p;
         return VIT_ENOMEM;
@@ -239,7 +263,7 @@ static int* tuning_field(Tuning& t, const char* key) {
         {"dense_songs", &Tuning::dense_songs}, {"dense_one_thread", &Tuning::dense_one_thread}, {"dense_form", &Tuning::dense_form},
         {"step_form", &Tuning::step_form}, {"bt_chunks", &Tuning::bt_chunks}, {"bt_warm", &Tuning::bt_warm},
         {"win_shift", &Tuning::win_shift}, {"wave_min_batch", &Tuning::wave_min_batch}, {"wave_two", &Tuning::wave_two},
-        {"wave_history", &Tuning::wave_history},
+        {"wave_history", &Tuning::wave_history}, {"wave_uniform", &Tuning::wave_uniform},
         {"timing", &Tuning::timing},
     };
     for (const auto& e : tab)
@@ -317,6 +341,7 @@ static void fwd_args_from_plan(const vit_plan* plan, vit::FwdArgs& a) {
     a.wave_ok = plan->bp.ok && plan->bp.wave_ok ? 1 : 0;
     a.wave_npl = plan->bp.wave_npl;
     a.wave_dk = plan->bp.wave_dk;
+    a.wave_u5 = tn.wave_uniform == 1 ? 0 : (tn.wave_uniform == 2 ? (plan->wave_u5 >= 1 ? 1 : 0) : plan->wave_u5);
     a.wave_flags = tn.wave_two == 1 ? 1 : (tn.wave_two == 2 ? 2 : 0);
     a.win_shift = (plan->bp.ok && plan->bp.lo_affine) ? (plan->bp.lo_off & 3) : 0;
     a.win_shift2 = (plan->bp.ok && plan->bp.pair_ok && plan->bp.lo2_affine) ? (plan->bp.lo2_off & 3) : 0;

@@ -147,7 +147,15 @@ __device__ __forceinline__ void store_row(float* __restrict__ p, const float (&d
 // HM 0 it cost the full-history kernel 25 %: 19.9 -> 25.1 ms at B = 1024): every row like HM 0, but FwdArgs::t_begin > 0 resumes from init_rows[song] = delta_{t_begin - 1} in
 // slot order (a checkpoint row; lane 0's scalar slots are idle slots and are reset to -inf), computes frames t_begin ..
 // min(t_end, T_b) - 1 and stores row t at t - t_begin; the terminal state is pass 1's business.
-template <int NPL, int D, int NX, int PF, int WPS, int HM, typename ET>
+//
+// UV >= 1 (one extra column and it is the last state, S - 1 = slot 64*NPL - 1 whatever S): delta of the extra column is a plain
+// v_readlane of lane 63's last slot instead of a select chain over the lane's slots (which the compiler turned into an LDS round
+// trip per frame).  UV = 2 (plan-proven, FwdArgs::wave_u5; NPL = 6) in addition: the row constant and the extra-column weight are the
+// same for a lane's slots 0..4 (the 360 voiced targets of the reference's matrices: log tiny, log(sw10 / n_bins); idle slots: -inf) and
+// only slot 5 -- lane 63's unvoiced target, lane 3's first state at S = 361 -- has its own.  Then fl(M + c), fl(delta_x + a_x) and
+// their maximum are formed ONCE per lane and once for slot 5 (4 adds + 2 max instead of 12 adds, and six two-operand maxima
+// instead of six max3), and delta of the extra column is a plain v_readlane of lane 63's slot 5.
+template <int NPL, int D, int NX, int PF, int WPS, int HM, typename ET, int UV = 0>
 __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
     constexpr int H = wave_halo(NPL, D);
     constexpr int NG = 2 * H + 1;              // lane groups of the neighbourhood
@@ -155,6 +163,9 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
     constexpr int SDW = 64 * NPL;              // history row stride of this form
     static_assert(NPL <= 8 && NPL % 2 == 0 && NX <= kWaveMaxExtras && NX + 1 <= NPL && PF >= 1, "geometry (source pairs never straddle two lanes)");
     static_assert(HM != 1 || 2 * (NX + 1) <= NPL, "half history: lane 0 carries the scalars of two frames");
+    static_assert(UV == 0 || NX == 1, "last-state / uniform-lane forms: one extra column");
+    static_assert(UV < 2 || NPL == 6, "uniform-lane form: six states per lane");
+    constexpr bool U5 = UV == 2;
     const int S = a.S, T = a.T;
     const int lane = threadIdx.x & 63;
     const int song = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -233,6 +244,7 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
     };
     // delta of the extra columns, wave-uniform
     auto extra_deltas = [&](const float (&d)[NPL], float (&xd)[NX > 0 ? NX : 1]) {
+        if (UV >= 1) { xd[0] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d[NPL - 1]), 63)); return; }   // state S-1 = lane 63, last slot
 #pragma unroll
         for (int x = 0; x < NX; ++x) {
             float v = d[0];
@@ -316,12 +328,18 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
             }
         }
         // ---- floor term, extra columns, emission
+        if (U5) {
+            const float ya = fmaxf(M + cj[0], xd[0] + xa[0][0]), yb = fmaxf(M + cj[NPL - 1], xd[0] + xa[0][NPL - 1]);
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) {
-            float m = fmaxf(acc[k], M + cj[k]);
+            for (int k = 0; k < NPL; ++k) d[k] = fmaxf(acc[k], k < NPL - 1 ? ya : yb) + e[k];
+        } else {
 #pragma unroll
-            for (int x = 0; x < NX; ++x) m = fmaxf(m, xd[x] + xa[x][k]);
-            d[k] = m + e[k];
+            for (int k = 0; k < NPL; ++k) {
+                float m = fmaxf(acc[k], M + cj[k]);
+#pragma unroll
+                for (int x = 0; x < NX; ++x) m = fmaxf(m, xd[x] + xa[x][k]);
+                d[k] = m + e[k];
+            }
         }
         const float Mp = M;                // the previous frame's scalars (wave-uniform: scalar registers)
         float xp[NX > 0 ? NX : 1];
@@ -412,9 +430,13 @@ static hipError_t launch_wave_x(const FwdArgs& a, hipStream_t st) {
         else hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 6, ET>), dim3(grid), dim3(256), 0, st, a);
     } else if (a.hist_half) {
         if (one) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF1, 1, 1, ET>), dim3(grid), dim3(256), 0, st, a);
+        else if (NX == 1 && NPL == 6 && a.wave_u5 == 2) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 1, ET, (NX == 1 && NPL == 6) ? 2 : 0>), dim3(grid), dim3(256), 0, st, a);
+        else if (NX == 1 && a.wave_u5 >= 1) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 1, ET, NX == 1 ? 1 : 0>), dim3(grid), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 1, ET>), dim3(grid), dim3(256), 0, st, a);
     } else {
         if (one) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF1, 1, 0, ET>), dim3(grid), dim3(256), 0, st, a);
+        else if (NX == 1 && NPL == 6 && a.wave_u5 == 2) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 0, ET, (NX == 1 && NPL == 6) ? 2 : 0>), dim3(grid), dim3(256), 0, st, a);
+        else if (NX == 1 && a.wave_u5 >= 1) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 0, ET, NX == 1 ? 1 : 0>), dim3(grid), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 0, ET>), dim3(grid), dim3(256), 0, st, a);
     }
     return hipGetLastError();
