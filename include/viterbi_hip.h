@@ -117,7 +117,8 @@ int vit_plan_query(const vit_plan *plan, vit_plan_info *info);
  *                      allow it (window 32 wide with an affine start, <= 2 extra columns, S <= 378)
  *   "wave_uniform"     wave form: 0 = specialised variants where the plan proves them -- the one extra column is the last state (every
  *                      matrix the reference builds), and a lane's slots 0..4 share the row constant and the extra-column weight
- *                      (its 361-state matrices) | 1 = neither | 2 = the first only
+ *                      (its 361-state matrices; for its 321-state ones three groups of slots do) | 1 = neither | 2 = the first only |
+ *                      3 = the three-group form also where two groups would do
  *   "timing"           ablation / probe mask: accepted only by a -DVIT_TIMING_HOOKS build (VIT_EUNSUPPORTED otherwise;
  *                      those bits change results)
  *   "reset"            back to the defaults

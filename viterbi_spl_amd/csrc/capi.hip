@@ -30,7 +30,7 @@ struct Tuning {
     int wave_two = 0;          // wave kernel: 1 always the 256-register instantiation (the default but for two extra columns) | 2 the 512-register
                                // one up to 1024 songs
     int wave_uniform = 0;      // wave form: 0 = the last-state / uniform-lane variants where the plan proves them (wave.hip UV) | 1 = neither |
-                               // 2 = the last-state variant only
+                               // 2 = the last-state variant only | 3 = the three-group form where the two-group one would run (it is valid there too)
     int wave_history = 0;      // wave form: 0 / 1 every delta row | 2 the rows of even frames only (VIT_EUNSUPPORTED where the plan does not allow it)
     int timing = 0;
 };
@@ -192,20 +192,23 @@ int vit_plan_create(const float* logA_T, const float* log_pi, int64_t S, vit_pla
         if (p->wave_u5 == 1 && p->bp.wave_npl == 6) {
             const float* xa = reinterpret_cast<const float*>(p->host_image.data() + p->L.off_extraA);
             const int o = 384 - (int)S;
-            bool ok = true;
-            for (int l = 0; l < 64 && ok; ++l) {
-                uint32_t c_ref = 0, x_ref = 0;
-                for (int k = 0; k < 5 && ok; ++k) {
-                    const int j = 6 * l + k - o;
-                    const float cv = j >= 0 ? p->bp.rowc[j] : -INFINITY, xv = j >= 0 ? xa[j] : -INFINITY;
-                    uint32_t cb, xb;
-                    std::memcpy(&cb, &cv, 4);
-                    std::memcpy(&xb, &xv, 4);
-                    if (k == 0) { c_ref = cb; x_ref = xb; }
-                    ok = cb == c_ref && xb == x_ref;
+            auto uniform = [&](const int k0, const int k1) {       // slots k0 .. k1-1 of every lane agree in row constant and extra-column weight
+                for (int l = 0; l < 64; ++l) {
+                    uint32_t c_ref = 0, x_ref = 0;
+                    for (int k = k0; k < k1; ++k) {
+                        const int j = 6 * l + k - o;
+                        const float cv = j >= 0 ? p->bp.rowc[j] : -INFINITY, xv = j >= 0 ? xa[j] : -INFINITY;
+                        uint32_t cb, xb;
+                        std::memcpy(&cb, &cv, 4);
+                        std::memcpy(&xb, &xv, 4);
+                        if (k == k0) { c_ref = cb; x_ref = xb; }
+                        if (cb != c_ref || xb != x_ref) return false;
+                    }
                 }
-            }
-            if (ok) p->wave_u5 = 2;
+                return true;
+            };
+            if (uniform(0, 5)) p->wave_u5 = 2;                      // S = 361: the idle slots end at a lane boundary + 5
+            else if (uniform(0, 3) && uniform(3, 5)) p->wave_u5 = 3;   // S = 321: they end in the middle of a lane
         }
     } catch (const std::bad_alloc&) {
         delete p;
@@ -341,7 +344,7 @@ static void fwd_args_from_plan(const vit_plan* plan, vit::FwdArgs& a) {
     a.wave_ok = plan->bp.ok && plan->bp.wave_ok ? 1 : 0;
     a.wave_npl = plan->bp.wave_npl;
     a.wave_dk = plan->bp.wave_dk;
-    a.wave_u5 = tn.wave_uniform == 1 ? 0 : (tn.wave_uniform == 2 ? (plan->wave_u5 >= 1 ? 1 : 0) : plan->wave_u5);
+    a.wave_u5 = tn.wave_uniform == 1 ? 0 : (tn.wave_uniform == 2 ? (plan->wave_u5 >= 1 ? 1 : 0) : (tn.wave_uniform == 3 && plan->wave_u5 == 2 ? 3 : plan->wave_u5));
     a.wave_flags = tn.wave_two == 1 ? 1 : (tn.wave_two == 2 ? 2 : 0);
     a.win_shift = (plan->bp.ok && plan->bp.lo_affine) ? (plan->bp.lo_off & 3) : 0;
     a.win_shift2 = (plan->bp.ok && plan->bp.pair_ok && plan->bp.lo2_affine) ? (plan->bp.lo2_off & 3) : 0;

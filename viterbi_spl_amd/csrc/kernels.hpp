@@ -60,7 +60,7 @@ struct FwdArgs {
     size_t off_tabV;        // wave form (wave.hip)
     int wave_ok, wave_npl, wave_dk;
     int wave_u5;            // wave.hip UV: 1 = the one extra column is state S-1; 2 = also: row constant and extra-column weight uniform over a
-                            // lane's slots 0..4
+                            // lane's slots 0..4; 3 = uniform over slots {0,1,2} and {3,4}
     int wave_flags;         // bit 0: force the 256-register (two waves per SIMD) instantiation, bit 1: the 512-register one up to 1024 songs
     int hist_half;          // wave form: 1 = only the delta rows of even frames are stored (wave.hip, HM 1)
     int64_t hist_rows;      // history rows per song: T, or (T + 1) / 2 with hist_half; checkpoint pass: segments + 1

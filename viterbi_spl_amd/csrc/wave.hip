@@ -154,7 +154,8 @@ __device__ __forceinline__ void store_row(float* __restrict__ p, const float (&d
 // same for a lane's slots 0..4 (the 360 voiced targets of the reference's matrices: log tiny, log(sw10 / n_bins); idle slots: -inf) and
 // only slot 5 -- lane 63's unvoiced target, lane 3's first state at S = 361 -- has its own.  Then fl(M + c), fl(delta_x + a_x) and
 // their maximum are formed ONCE per lane and once for slot 5 (4 adds + 2 max instead of 12 adds, and six two-operand maxima
-// instead of six max3), and delta of the extra column is a plain v_readlane of lane 63's slot 5.
+// instead of six max3), and delta of the extra column is a plain v_readlane of lane 63's slot 5.  UV = 3: the same with three groups of
+// slots, {0,1,2} {3,4} {5} -- S = 321 (msnet / dcnet / ftanet), whose idle slots end in the middle of lane 10 (6 adds + 3 max).
 template <int NPL, int D, int NX, int PF, int WPS, int HM, typename ET, int UV = 0>
 __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
     constexpr int H = wave_halo(NPL, D);
@@ -164,8 +165,8 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
     static_assert(NPL <= 8 && NPL % 2 == 0 && NX <= kWaveMaxExtras && NX + 1 <= NPL && PF >= 1, "geometry (source pairs never straddle two lanes)");
     static_assert(HM != 1 || 2 * (NX + 1) <= NPL, "half history: lane 0 carries the scalars of two frames");
     static_assert(UV == 0 || NX == 1, "last-state / uniform-lane forms: one extra column");
-    static_assert(UV < 2 || NPL == 6, "uniform-lane form: six states per lane");
-    constexpr bool U5 = UV == 2;
+    static_assert(UV < 2 || NPL == 6, "uniform-lane forms: six states per lane");
+    constexpr bool U5 = UV == 2, U3 = UV == 3;
     const int S = a.S, T = a.T;
     const int lane = threadIdx.x & 63;
     const int song = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -332,6 +333,11 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
             const float ya = fmaxf(M + cj[0], xd[0] + xa[0][0]), yb = fmaxf(M + cj[NPL - 1], xd[0] + xa[0][NPL - 1]);
 #pragma unroll
             for (int k = 0; k < NPL; ++k) d[k] = fmaxf(acc[k], k < NPL - 1 ? ya : yb) + e[k];
+        } else if (U3) {
+            const float ya = fmaxf(M + cj[0], xd[0] + xa[0][0]), yb = fmaxf(M + cj[3], xd[0] + xa[0][3]);
+            const float yc = fmaxf(M + cj[NPL - 1], xd[0] + xa[0][NPL - 1]);
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) d[k] = fmaxf(acc[k], k < 3 ? ya : (k < NPL - 1 ? yb : yc)) + e[k];
         } else {
 #pragma unroll
             for (int k = 0; k < NPL; ++k) {
@@ -431,11 +437,13 @@ static hipError_t launch_wave_x(const FwdArgs& a, hipStream_t st) {
     } else if (a.hist_half) {
         if (one) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF1, 1, 1, ET>), dim3(grid), dim3(256), 0, st, a);
         else if (NX == 1 && NPL == 6 && a.wave_u5 == 2) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 1, ET, (NX == 1 && NPL == 6) ? 2 : 0>), dim3(grid), dim3(256), 0, st, a);
+        else if (NX == 1 && NPL == 6 && a.wave_u5 == 3) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 1, ET, (NX == 1 && NPL == 6) ? 3 : 0>), dim3(grid), dim3(256), 0, st, a);
         else if (NX == 1 && a.wave_u5 >= 1) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 1, ET, NX == 1 ? 1 : 0>), dim3(grid), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 1, ET>), dim3(grid), dim3(256), 0, st, a);
     } else {
         if (one) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF1, 1, 0, ET>), dim3(grid), dim3(256), 0, st, a);
         else if (NX == 1 && NPL == 6 && a.wave_u5 == 2) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 0, ET, (NX == 1 && NPL == 6) ? 2 : 0>), dim3(grid), dim3(256), 0, st, a);
+        else if (NX == 1 && NPL == 6 && a.wave_u5 == 3) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 0, ET, (NX == 1 && NPL == 6) ? 3 : 0>), dim3(grid), dim3(256), 0, st, a);
         else if (NX == 1 && a.wave_u5 >= 1) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 0, ET, NX == 1 ? 1 : 0>), dim3(grid), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 0, ET>), dim3(grid), dim3(256), 0, st, a);
     }
