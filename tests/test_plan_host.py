@@ -145,10 +145,10 @@ def test_banded_with_minus_inf_floor():
     assert np.array_equal(st, ref) and delta.tobytes() == rdelta.tobytes()
 
 
-@pytest.mark.parametrize("n_bins,d_max,W", [(721, 40, 96), (499, 56, 128), (721, 30, 64)])
+@pytest.mark.parametrize("n_bins,d_max,W", [(721, 40, 84), (721, 46, 96), (499, 56, 128), (721, 30, 64)])
 def test_wide_bands_of_the_high_resolution_grids(n_bins, d_max, W):
     """jdc: d_max = 40 on the 721-bin grid (82 + unvoiced exceptions per row), imm: d_max = 56; the plan proves them
-    banded with W = 96 / 128 and the floor-max form replays bit for bit."""
+    banded with W = 84 / 128 (84: the narrowest whole-float4 window over the 81 sources of a row; 96 for a wider band) and the floor-max form replays bit for bit."""
     logA_T, log_pi = synth.log_params(synth.tonet_transition(n_bins, d_max), synth.floored_prior(n_bins + 1))
     plan = HostPlan(logA_T, log_pi)
     assert plan.ok and plan.W == W and plan.max_window == 2 * d_max + 1 and plan.extras == [n_bins] and plan.n_dense == 0

@@ -1520,6 +1520,14 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
             m2 = fmaxf(fmaxf(m2, c2_.x), c2_.y);
             m3 = fmaxf(fmaxf(m3, c3_.x), c3_.y);
         }
+        if (W % 8 == 4 && w0 + 32 >= W) {          // W = 84: the last four sources (one read, two packed adds)
+            static_assert(W % 8 != 4 || W <= WR, "an odd float4 count only with register-resident weights");
+            const f32x4 da = dw[((W - 4 - w0) / 4) & 7];
+            const f32x2 c0_ = f32x2{da.x, da.y} + f32x2{aw[W - 4], aw[W - 3]};
+            const f32x2 c1_ = f32x2{da.z, da.w} + f32x2{aw[W - 2], aw[W - 1]};
+            m2 = fmaxf(fmaxf(m2, c0_.x), c0_.y);
+            m3 = fmaxf(fmaxf(m3, c1_.x), c1_.y);
+        }
         }
 #pragma unroll
         for (int k = 0; k < NXL; ++k) m1 = fmaxf(m1, xd[k] + xa[k]);
@@ -2455,8 +2463,8 @@ static hipError_t launch_floor_t(const FwdArgs& a, hipStream_t st) {
     constexpr int NWM = (NWT + 3) / 4 * 4;
     const size_t ldsf = sizeof(float) * (8 * (NP + 16) + 2 * NWM + 64 + NWM) + sizeof(VI) * 16 +
                         ((W == 128 && NWT > 8) ? sizeof(f32x4) * 8 * NP : 0);
-    if ((W == 32 || W >= 96) && a.n_extras == 1)   // the reference's matrices: band + unvoiced column (compile-time extras count)
-        hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, ((W == 32 || W >= 96) ? 1 : -1), PF, ET>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
+    if ((W == 32 || W >= 84) && a.n_extras == 1)   // the reference's matrices: band + unvoiced column (compile-time extras count)
+        hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, ((W == 32 || W >= 84) ? 1 : -1), PF, ET>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
     else
         hipLaunchKernelGGL((banded_floor_forward_kernel<W, NWT, -1, PF, ET>), dim3((int)a.B), dim3(NWT * 64), ldsf, st, a);
     return hipGetLastError();
@@ -2515,6 +2523,7 @@ static hipError_t launch_banded_e(const FwdArgs& a, hipStream_t st) {
         case 16: return launch_banded_w<16, ET>(a, st);
         case 32: return launch_banded_w<32, ET>(a, st);
         case 64: return launch_banded_w<64, ET>(a, st);
+        case 84: return launch_banded_w<84, ET>(a, st);
         case 96: return launch_banded_w<96, ET>(a, st);
         case 128: return launch_banded_w<128, ET>(a, st);
         default: return hipErrorInvalidConfiguration;

@@ -17,7 +17,7 @@ static inline uint32_t f2u(float f) {
 
 static inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
-static const int kWidths[] = {16, 32, 64, 96, 128};  // window widths the banded kernels are instantiated for
+static const int kWidths[] = {16, 32, 64, 84, 96, 128};  // window widths the banded kernels are instantiated for
 
 BandedPlan analyze_banded(const float* A, int S) {
     BandedPlan bp;
