@@ -1487,9 +1487,17 @@ __global__ void __launch_bounds__(NWT * 64) banded_floor_forward_kernel(FwdArgs 
         // twelve waves per workgroup the other waves of the SIMD cover the read latency)
         if ((W > 64 || (W == 64 && NWT > 8)) && w0 > 0) asm volatile("" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3)::"memory");
         f32x4 dw[8];
+#ifdef VIT_ABL_READS
+        // result-breaking ablation (make TIMING=1 ABL=n builds only): read n of every chunk's window quads, the others reuse them --
+        // what does the LDS return path cost a frame?
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (w0 + 4 * q < W) { if (q < VIT_ABL_READS) dw[q] = win[w0 / 4 + q]; else dw[q] = dw[q % VIT_ABL_READS]; }
+#else
 #pragma unroll
         for (int q = 0; q < 8; ++q)
             if (w0 + 4 * q < W) dw[q] = win[w0 / 4 + q];
+#endif
         if (w0 == 0) {
             __builtin_amdgcn_sched_barrier(0);
             // M = max of delta_{t-1} over the non-extra sources
