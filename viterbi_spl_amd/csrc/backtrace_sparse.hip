@@ -37,6 +37,11 @@ __device__ __forceinline__ int sp_song_length(const int64_t* lengths, int song, 
     v = v < 1 ? 1 : v;
     return v > T ? T : (int)v;
 }
+__device__ __forceinline__ int sp_clamp(int x, int hi) {   // min(max(x, 0), hi): one v_med3_i32
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi));
+    return r;
+}
 __device__ __forceinline__ float sp_wave_max(float x) {   // kernels.hip wave_max_all
     asm volatile(
         "s_nop 1\n\t"
@@ -132,6 +137,10 @@ __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
         xcol[e] = x;
     }
     const int lo_max = S - W;
+    // at most one extra column and it is the last state (the unvoiced state of the reference's matrices): no index is above it
+    const bool fast_rows = KC == 1 && (nx == 0 || (nx == 1 && a.extras[0] == S - 1));
+    // fast rows: byte offset of this lane's candidate in a tile row = wlo * fr_mul + fr_off (window lanes move with the window start)
+    const unsigned fr_mul = isw[0] ? 4u : 0u, fr_off = 4u * (unsigned)(isw[0] ? lane : kSpNS + auxi[0]);
     const int c0_max = (SD - kSpNS) & ~3;    // (rows are 16-byte aligned; the clamp may leave the last span 16-byte aligned only)
 
     int n_tiles = 0, n_miss = 0, n_full = 0, n_rep = 0, n_repf = 0;      // event counts of this wave (vit_backtrace_counters)
@@ -182,6 +191,34 @@ __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
             for (int r = __builtin_amdgcn_readfirstlane(rows - 1); r >= 0; --r) {
                 cur = __builtin_amdgcn_readfirstlane(cur);
                 constexpr bool kLean = AFF && KC == 1 && !GT;          // the reference's S = 321 / 361 matrices
+                if constexpr (kLean) {
+                    if (fast_rows) {
+                        // ---- the unexceptional rows, in a loop of their own with ONE early exit: the window fits the span, the bound
+                        //      candidate stays below the maximum and a window candidate attains it.  The one extra column is the last state
+                        //      (fast_rows), so the lowest window match is the lowest match whatever the extra candidate holds.  Any
+                        //      other row falls through to the general code below, which evaluates it again from scratch.
+                        for (;;) {
+                            int curv;
+                            asm volatile("v_mov_b32 %0, %1" : "=v"(curv) : "s"(cur));
+                            const int lov = sp_clamp(curv - a.lo_off, lo_max);
+                            const int wlov = lov + (a.col0 - c0);
+                            // (a window that left the span reads entries of the tile that are not its own -- or nothing: LDS reads beyond the
+                            //  allocation return zero -- and the row is an exceptional one whatever they hold)
+                            const float dv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(tile + r * kSpRS) + __umul24(wlov, fr_mul) + fr_off);
+                            const float vv = dv + tabX[__umul24(curv, WX1) + tb[0]];
+                            const float mx = sp_wave_max(cand[0] ? vv : -INFINITY);
+                            const unsigned long long ge = __ballot(vv >= mx) & cand_or_bound;
+                            if ((__ballot((unsigned)wlov > (unsigned)(kSpNS - W)) | (ge & (1ull << CB))) != 0) break;
+                            const unsigned long long gw = ge & wmask[0];
+                            if (gw == 0) break;
+                            cur = __builtin_amdgcn_readfirstlane(lov) + __builtin_ctzll(gw);
+                            outv = lane == r ? cur : outv;
+                            if (MODE == 1 && cur == __builtin_amdgcn_readlane(oldv, r)) { rstop = r; break; }
+                            if (--r < 0) break;
+                        }
+                        if (r < 0 || rstop >= 0) break;
+                    }
+                }
                 int lo;
                 float v[KC], av[KC];
                 float m;
