@@ -39,6 +39,7 @@ constexpr int kHbAux = 8;           // scalars per stored row (the row's first e
 constexpr int kHbW = 32;            // window width (the wave form exists for half-widths up to 14)
 constexpr int kHbTile = kHbR * kHbND + (kHbR + 1) * kHbAux + kHbR * kHbNE;   // floats per wave
 constexpr int kHbWX1 = kHbW + kMaxExtras + 1;
+constexpr int kHbWXS = (kHbWX1 + 3) / 4 * 4;      // row stride of the candidate table in LDS: 16-byte aligned rows (and halves of a window)
 constexpr int kHbCB = kHbW + kMaxExtras;    // candidate lane of the bound
 
 __device__ __forceinline__ int hb_song_length(const int64_t* lengths, int song, int T) {
@@ -46,6 +47,11 @@ __device__ __forceinline__ int hb_song_length(const int64_t* lengths, int song, 
     long long v = lengths[song];
     v = v < 1 ? 1 : v;
     return v > T ? T : (int)v;
+}
+__device__ __forceinline__ int hb_clamp(int x, int hi) {   // min(max(x, 0), hi): one v_med3_i32
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi));
+    return r;
 }
 __device__ __forceinline__ float hb_wave_max(float x) {   // kernels.hip wave_max_all
     asm volatile(
@@ -85,18 +91,18 @@ __device__ __forceinline__ float hb_ld<__half>(const __half* p) { return __half2
 template <int MODE, typename ET>
 __global__ void __launch_bounds__(1024) half_backtrace_kernel(BtArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int EPL = 6, W = kHbW, WX1 = kHbWX1, CB = kHbCB;
+    constexpr int EPL = 6, W = kHbW, WX1 = kHbWX1, WXS = kHbWXS, CB = kHbCB;
     const int S = a.S, SP = a.SP, SD = a.SD, T = a.T;
     const int nx = a.n_extras;
     const int nwaves = blockDim.x >> 6;
     float* tiles = reinterpret_cast<float*>(smem);                            // [nwaves][kHbTile]
-    float* tabX = tiles + nwaves * kHbTile;                                   // [SP][WX1]
+    float* tabX = tiles + nwaves * kHbTile;                                   // [SP][WXS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     {
         const float* __restrict__ gtab = reinterpret_cast<const float*>(a.image + a.off_tabX);
         const int nthr = blockDim.x;
-        for (int k = tid; k < SP * WX1; k += nthr) tabX[k] = gtab[k];
+        for (int k = tid; k < SP * WX1; k += nthr) tabX[(k / WX1) * WXS + k % WX1] = gtab[k];
     }
     __syncthreads();
 
@@ -133,6 +139,7 @@ __global__ void __launch_bounds__(1024) half_backtrace_kernel(BtArgs a) {
         xcol[e] = x;
     }
     const int lo_max = S - W, lo_off = a.lo_off;
+    const bool fast_rows = nx == 0 || (nx == 1 && a.extras[0] == S - 1);      // no index above the one extra column
     auto lo_of = [&](const int j) -> int { const int l = j - lo_off; return l < 0 ? 0 : (l > lo_max ? lo_max : l); };
     const int c0_max = (SD - kHbND) & ~3;
     const int ce_max = S - kHbNE;
@@ -216,6 +223,62 @@ __global__ void __launch_bounds__(1024) half_backtrace_kernel(BtArgs a) {
             const int lane_mg = lane - g;                                   // span column of window candidate `lane`, relative to lo
             for (int f = __builtin_amdgcn_readfirstlane(top); f >= first; --f) {
                 cur = __builtin_amdgcn_readfirstlane(cur);
+                if (fast_rows) {
+                    // ---- the unexceptional frames in a loop of their own with direct exits (backtrace_sparse.hip, fast rows): the window
+                    //      start inside the tile's interval, the bound candidate below the maximum, a window candidate attaining it (the one
+                    //      extra column is the last state, so the lowest window match is the lowest match).  Any other frame falls through
+                    //      to the general code below, which evaluates it again from scratch.
+                    for (;;) {
+                        int curv;
+                        asm volatile("v_mov_b32 %0, %1" : "=v"(curv) : "s"(cur));
+                        const int lov = hb_clamp(curv - lo_off, lo_max);
+                        const int rr = (f >> 1) - r_lo;
+                        const int rowd = rr * kHbND, rowa = rr * kHbAux;
+                        float dv;
+                        if (f & 1) {
+                            const int iv = lov + il;
+                            const int li = hb_clamp(iv - lo_off, lo_max);
+                            const float* __restrict__ src = td + (rowd - g + 16 * hh) + li;
+                            const float* __restrict__ wt = tabX + __umul24(iv, WXS);
+                            // every read of the rebuild goes out before the first sum (left alone the compiler reads a pair, waits, adds: eight
+                            // LDS round trips in a row); the sixteen weights of this half are four aligned quads (row stride WXS)
+                            const f32x4* __restrict__ wq = reinterpret_cast<const f32x4*>(wt + 16 * hh);
+                            f32x4 w4[4];
+                            float sv[16];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) w4[q] = wq[q];
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) sv[q] = src[q];
+                            const float* __restrict__ ar = ta + rowa;
+                            const float fl_ = ar[a.mcol] + wt[CB];
+                            const float xt_ = nx ? ar[a.xcol0] + wt[W] : -INFINITY;
+                            asm volatile("" ::: "memory");
+                            float acc0 = -INFINITY, acc1 = -INFINITY;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                acc0 = fmaxf(fmaxf(acc0, sv[4 * q] + w4[q].x), sv[4 * q + 2] + w4[q].z);
+                                acc1 = fmaxf(fmaxf(acc1, sv[4 * q + 1] + w4[q].y), sv[4 * q + 3] + w4[q].w);
+                            }
+                            float acc = hb_other_half(fmaxf(acc0, acc1));
+                            acc = fmaxf(fmaxf(acc, fl_), xt_);
+                            const float dw = acc + te[rr * kHbNE - ce0 + iv];
+                            dv = isw ? dw : ta[rowa + kHbAux + aux_odd];
+                        } else {
+                            dv = (isw ? td + rowd + lov + lane_mg : ta + rowa + aux_even)[0];
+                        }
+                        const float v = dv + tabX[__umul24(curv, WXS) + tb];
+                        const float m = hb_wave_max(cand ? v : -INFINITY);
+                        const unsigned long long ge = __ballot(v >= m) & cand_or_bound;
+                        if ((__ballot((unsigned)(lov - lo_a) > lo_span) | (ge & (1ull << CB))) != 0) break;
+                        const unsigned gw = (unsigned)ge;                      // (W = 32: the window candidates are lanes 0 .. 31)
+                        if (gw == 0) break;
+                        cur = __builtin_amdgcn_readfirstlane(lov) + __builtin_ctz(gw);
+                        outv = lane == f - first ? cur : outv;
+                        if (MODE == 1 && cur == __builtin_amdgcn_readlane(oldv, f - first)) { fstop = f; fdone = f + 1; break; }
+                        if (--f < first) break;
+                    }
+                    if (f < first || fstop >= 0) break;
+                }
                 int curv;
                 asm volatile("v_mov_b32 %0, %1" : "=v"(curv) : "s"(cur));
                 int lov = curv - lo_off;
@@ -230,7 +293,7 @@ __global__ void __launch_bounds__(1024) half_backtrace_kernel(BtArgs a) {
                     int li = iv - lo_off;
                     li = li < 0 ? 0 : (li > lo_max ? lo_max : li);         // start of ITS window
                     const float* __restrict__ src = td + (rowd - g + 16 * hh) + li;
-                    const float* __restrict__ wt = tabX + iv * WX1;
+                    const float* __restrict__ wt = tabX + iv * WXS;
                     float acc0 = -INFINITY, acc1 = -INFINITY;
 #pragma unroll
                     for (int q = 0; q < 16; q += 2) {
@@ -246,7 +309,7 @@ __global__ void __launch_bounds__(1024) half_backtrace_kernel(BtArgs a) {
                 } else {
                     dv = (isw ? td + rowd + lov + lane_mg : ta + rowa + aux_even)[0];
                 }
-                const float av = tabX[curv * WX1 + tb];
+                const float av = tabX[curv * WXS + tb];
                 float v = dv + av;
                 const float vc = cand ? v : -INFINITY;
                 const float m = hb_wave_max(vc);
@@ -289,7 +352,7 @@ __global__ void __launch_bounds__(1024) half_backtrace_kernel(BtArgs a) {
                             const int i = e * 64 + lane;
                             const int ic = inS[e] ? i : S - 1;
                             const float* __restrict__ src = td + lo_of(ic);
-                            const float* __restrict__ wt = tabX + ic * WX1;
+                            const float* __restrict__ wt = tabX + ic * WXS;
                             float acc = Mp + wt[CB];
 #pragma unroll 8
                             for (int w = 0; w < W; ++w) acc = fmaxf(acc, src[w] + wt[w]);
@@ -396,7 +459,7 @@ __global__ void __launch_bounds__(1024) half_backtrace_kernel(BtArgs a) {
 }
 
 static size_t half_lds_bytes(const BtArgs& a, int nwaves) {
-    return sizeof(float) * ((size_t)nwaves * kHbTile + (size_t)a.SP * kHbWX1);
+    return sizeof(float) * ((size_t)nwaves * kHbTile + (size_t)a.SP * kHbWXS);
 }
 
 // Half histories are written for plans whose window is 32 wide with an affine start (every matrix the wave form takes
