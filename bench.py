@@ -153,6 +153,7 @@ def time_overlapped(dec, E, algo, steps, warmup=1, lengths=None):
         dec._workspace(B, T, k, algo)
     s_fwd, s_bt = torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev)   # forward workgroups are dispatched first
     bt_done = [None, None]
+    dec.set_option("bt_chunks", dec.chunks_beside_forward(B))      # the back-trace on the units the forward pass leaves idle
 
     def run(n):
         for i in range(n):
@@ -175,6 +176,7 @@ def time_overlapped(dec, E, algo, steps, warmup=1, lengths=None):
     run(steps)
     wall = (time.perf_counter() - t0) / steps * 1e3
     dec._ws_slots.clear()
+    dec.set_option("bt_chunks", 0)
     return wall, st[(steps - 1) & 1], ll[(steps - 1) & 1]
 
 
@@ -460,6 +462,9 @@ def main():
     bt_done = [None] * NSLOT        # event: back-trace of the batch in this slot finished
     s_fwd = torch.cuda.Stream(device=dev, priority=-1)        # the forward pass is the critical path: its workgroups go first
     s_bt = torch.cuda.Stream(device=dev) if not args.serial else s_fwd
+    user_chunks = any(kv.split("=")[0] == "bt_chunks" for kv in args.option)
+    if s_bt is not s_fwd and not user_chunks:
+        dec.set_option("bt_chunks", dec.chunks_beside_forward(B))   # the back-trace on the units the forward pass leaves idle (0 = the library's count)
 
     def step(i, ev=None):
         k = pipe.acquire(i) if pipe is not None else i % NSLOT     # (waits for gather(i - NSLOT), which still reads states_k[k])
@@ -565,6 +570,7 @@ def main():
                        "algo": algo, "forward_kernel": fwd_kernel, "plan": dec.info, "options": args.option},
             "schedule": ("one stream: forward, back-trace" + (", gather" if use_dist else "") + " of a step back to back") if args.serial else
                         ("two streams: back-trace of step i overlaps the forward pass of step i+1; two workspace slots" +
+                         (f"; bt_chunks = {dec.chunks_beside_forward(B)} (the back-trace on the compute units the forward pass leaves idle)" if not user_chunks and dec.chunks_beside_forward(B) else "") +
                          ("; non-blocking gather on the communicator's stream" if use_dist else "")),
             "distributed": None if not use_dist else {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": ranks_info,
                                                       "gathers_launched_on_rank0": pipe.launched, "gather": "non-blocking dist.gather of states [B,T] int32 + loglik [B] to rank 0 per step"},
@@ -594,7 +600,9 @@ def main():
                     out["roofline"]["traffic_over_algorithmic"] = pm[fwd_kernel]["hbm_bytes_per_launch"] / fwd_bytes
                     out["backtrace"]["traffic"] = sum(pm[k]["hbm_bytes_per_launch"] for k in bt_names) if bt_names else None
                     out["pmc"] = pm
-            if not args.serial:        # the same steps without the overlap, for the record
+            if not args.serial:        # the same steps without the overlap, for the record (the library's own chunk count)
+                if not user_chunks:
+                    dec.set_option("bt_chunks", 0)
                 ser, _, _ = time_serial(dec, E, algo, steps=3)
                 out["serial_schedule"] = {**ser, "Mframes_per_s": B * T / ser["wall_ms_per_step"] / 1e3}
             if not args.no_cpu_baseline:

@@ -109,7 +109,8 @@ int vit_plan_query(const vit_plan *plan, vit_plan_info *info);
  *                      "dense_form" 0 = matrix-resident dense kernel where it applies (64 < S <= 368), 1 = always stream the matrix
  *   "step_form"        step-structured kernel: 0 four targets per lane, bands split over two waves | 1 one target per lane |
  *                      2 off (plain dense kernel) | 3 four targets per lane, one wave per lane group
- *   "bt_chunks", "bt_warm"   time-parallel back-trace: chunks per song (0 auto), warm-up frames (-1 default)
+ *   "bt_chunks", "bt_warm"   time-parallel back-trace: chunks per song (0 auto), warm-up frames (-1 default); "bt_fast_rows" 1 = every
+ *                      row through the general code of the sparse kernels (0: the unexceptional rows run in a loop of their own)
  *   "win_shift"        LDS window shift 0..3 (-1 from the plan); "wave_min_batch" (0 default), "wave_two" 1
  *   "wave_history"     wave form: 0 / 1 = store every delta row | 2 = store the rows of even frames only (the back-trace rebuilds
  *                      the 32 values an odd frame needs from the row before it and the emissions): half the workspace and a

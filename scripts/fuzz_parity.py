@@ -81,6 +81,7 @@ while time.time() - t0 < budget:
         n_cases += 1
         for algo, btf in forms:
             dec.set_option("backtrace_form", btf)
+            dec.set_option("bt_fast_rows", n_cases % 3 == 0)      # every third case: all rows through the sparse kernels' general code
             if chunks:
                 dec.set_option("bt_chunks", chunks)
                 dec.set_option("bt_warm", warm)

@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(1024) half_backtrace_kernel(BtArgs a) {
         xcol[e] = x;
     }
     const int lo_max = S - W, lo_off = a.lo_off;
-    const bool fast_rows = nx == 0 || (nx == 1 && a.extras[0] == S - 1);      // no index above the one extra column
+    const bool fast_rows = !a.no_fast_rows && (nx == 0 || (nx == 1 && a.extras[0] == S - 1));      // no index above the one extra column
     auto lo_of = [&](const int j) -> int { const int l = j - lo_off; return l < 0 ? 0 : (l > lo_max ? lo_max : l); };
     const int c0_max = (SD - kHbND) & ~3;
     const int ce_max = S - kHbNE;
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(1024) half_backtrace_kernel(BtArgs a) {
                         const unsigned gw = (unsigned)ge;                      // (W = 32: the window candidates are lanes 0 .. 31)
                         if (gw == 0) break;
                         cur = __builtin_amdgcn_readfirstlane(lov) + __builtin_ctz(gw);
-                        outv = lane == f - first ? cur : outv;
+                        asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(outv) : "s"(cur), "s"(f - first) : "m0");   // lane <- cur (instead of move, compare, select)
                         if (MODE == 1 && cur == __builtin_amdgcn_readlane(oldv, f - first)) { fstop = f; fdone = f + 1; break; }
                         if (--f < first) break;
                     }

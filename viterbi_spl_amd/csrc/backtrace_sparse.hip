@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
     }
     const int lo_max = S - W;
     // at most one extra column and it is the last state (the unvoiced state of the reference's matrices): no index is above it
-    const bool fast_rows = KC == 1 && (nx == 0 || (nx == 1 && a.extras[0] == S - 1));
+    const bool fast_rows = KC == 1 && !a.no_fast_rows && (nx == 0 || (nx == 1 && a.extras[0] == S - 1));
     // fast rows: byte offset of this lane's candidate in a tile row = wlo * fr_mul + fr_off (window lanes move with the window start)
     const unsigned fr_mul = isw[0] ? 4u : 0u, fr_off = 4u * (unsigned)(isw[0] ? lane : kSpNS + auxi[0]);
     const int c0_max = (SD - kSpNS) & ~3;    // (rows are 16-byte aligned; the clamp may leave the last span 16-byte aligned only)
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
                             const unsigned long long gw = ge & wmask[0];
                             if (gw == 0) break;
                             cur = __builtin_amdgcn_readfirstlane(lov) + __builtin_ctzll(gw);
-                            outv = lane == r ? cur : outv;
+                            asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(outv) : "s"(cur), "s"(r) : "m0");   // lane <- cur (instead of move, compare, select)
                             if (MODE == 1 && cur == __builtin_amdgcn_readlane(oldv, r)) { rstop = r; break; }
                             if (--r < 0) break;
                         }

@@ -31,6 +31,7 @@ struct Tuning {
                                // one up to 1024 songs
     int wave_uniform = 0;      // wave form: 0 = the last-state / uniform-lane variants where the plan proves them (wave.hip UV) | 1 = neither |
                                // 2 = the last-state variant only | 3 = the three-group form where the two-group one would run (it is valid there too)
+    int bt_fast_rows = 0;      // sparse / half back-trace: 0 = the unexceptional rows in their own loop | 1 = every row through the general code
     int wave_history = 0;      // wave form: 0 / 1 every delta row | 2 the rows of even frames only (VIT_EUNSUPPORTED where the plan does not allow it)
     int timing = 0;
 };
@@ -266,7 +267,7 @@ static int* tuning_field(Tuning& t, const char* key) {
         {"dense_songs", &Tuning::dense_songs}, {"dense_one_thread", &Tuning::dense_one_thread}, {"dense_form", &Tuning::dense_form},
         {"step_form", &Tuning::step_form}, {"bt_chunks", &Tuning::bt_chunks}, {"bt_warm", &Tuning::bt_warm},
         {"win_shift", &Tuning::win_shift}, {"wave_min_batch", &Tuning::wave_min_batch}, {"wave_two", &Tuning::wave_two},
-        {"wave_history", &Tuning::wave_history}, {"wave_uniform", &Tuning::wave_uniform},
+        {"bt_fast_rows", &Tuning::bt_fast_rows}, {"wave_history", &Tuning::wave_history}, {"wave_uniform", &Tuning::wave_uniform},
         {"timing", &Tuning::timing},
     };
     for (const auto& e : tab)
@@ -439,6 +440,7 @@ static void bt_args_from_plan(const vit_plan* plan, vit::BtArgs& b) {
     for (int k = 0; k < vit::kMaxExtras; ++k) b.extras[k] = plan->bp.extras[k];
     b.c0 = plan->bp.c0;
     b.bt_form = plan->tune.backtrace_form;
+    b.no_fast_rows = plan->tune.bt_fast_rows == 1 ? 1 : 0;
     b.lo_affine = plan->bp.lo_affine ? 1 : 0;
     b.lo_off = plan->bp.lo_off;
     for (int d = 0; d < vit::kMaxDenseRows; ++d) b.dense_rows[d] = d < plan->bp.n_dense ? plan->bp.dense_rows[d] : -1;

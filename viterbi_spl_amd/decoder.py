@@ -89,6 +89,17 @@ class ViterbiDecoder:
         same bits; ``set_option("reset", 0)`` restores the defaults."""
         _lib.check(_lib.load().vit_plan_set_option(self._plan, key.encode(), int(value)), f"vit_plan_set_option({key})")
 
+    def chunks_beside_forward(self, B: int) -> int:
+        """``bt_chunks`` for the two-stream schedule (the back-trace of batch i beside the forward pass of batch i + 1): while one
+        song per workgroup leaves compute units idle (B below the CU count), the back-trace gets the chunks that fill THOSE units
+        -- sixteen waves each -- instead of every unit of the chip, where its workgroups sit next to the latency-bound forward
+        workgroups and slow them down (B = 128: 10.04 instead of 10.22 ms per step, scripts/overlap_ab.py).  0 = the library's own
+        count (what a single stream should use: the back-trace alone is fastest with every unit)."""
+        n_cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        if B <= 0 or B >= n_cus:
+            return 0
+        return max(1, min(64, 16 * (n_cus - B) // B))
+
     # ------------------------------------------------------------------ workspace
     def workspace_bytes(self, B: int, T: int, algo: Optional[str] = None) -> int:
         """Bytes of workspace a [B,T,S] decode needs: for one `algo` (``vit_workspace_bytes_for`` -- the wave form keeps
