@@ -98,7 +98,7 @@ class ViterbiDecoder:
         n_cus = torch.cuda.get_device_properties(self.device).multi_processor_count
         if B <= 0 or B >= n_cus:
             return 0
-        return max(1, min(64, 16 * (n_cus - B) // B))
+        return max(1, min(32, 16 * (n_cus - B) // B))      # (32: the library's cap, kBtMaxChunks)
 
     # ------------------------------------------------------------------ workspace
     def workspace_bytes(self, B: int, T: int, algo: Optional[str] = None) -> int:
