@@ -22,6 +22,8 @@ Rank 0 prints ONE JSON line (always the last line of stdout).  At N = 1 it also 
              songs -- which doubles as a parity check of the GPU result -- and the C restatement on all cores.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without torchrun's environment: launches its own N workers,
+                                                            launch_workers() below, and relays rank 0's JSON line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 """
@@ -43,6 +45,47 @@ sys.path.insert(0, ROOT)
 from viterbi_spl_amd import ViterbiDecoder, sharded, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def launch_workers(n, argv, child=None, timeout=None):
+    """Start `n` worker processes of `child` (default: this file) under torch.distributed.run on this node (one rank per GPU,
+    rendezvous on 127.0.0.1 at a free port, HSA_ENABLE_IPC_MODE_LEGACY=0 kept for RCCL), pass their output through, and print
+    the LAST JSON line of their stdout (rank 0's result) as this process's own last stdout line.  Returns the workers' exit
+    code (non-zero if any rank failed, or if no JSON line came back).  The calling process must not have initialised the
+    GPU: the workers are children, nothing is re-executed in place."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), child or os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    last_json = None
+    try:
+        for line in proc.stdout:
+            ls = line.strip()
+            if ls.startswith("{") and ls.endswith("}"):
+                if last_json is not None:
+                    print(last_json, flush=True)       # an earlier JSON-looking line is ordinary output after all
+                last_json = ls
+            else:
+                sys.stdout.write(line)
+                sys.stdout.flush()
+        rc = proc.wait(timeout=timeout)
+    except BaseException:
+        proc.kill()
+        proc.wait()
+        raise
+    if last_json is not None:
+        print(last_json, flush=True)
+    elif rc == 0:
+        rc = 1
+    return rc
 
 
 def parse():
@@ -431,9 +474,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process has not touched the GPU; its N workers are children (no re-exec)
+        raise SystemExit(launch_workers(args.gpus, sys.argv[1:]))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, or plainly")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"     # the latter: rehearse the gather path on one GPU

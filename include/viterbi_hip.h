@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VIT_ABI_VERSION 3
+#define VIT_ABI_VERSION 4
 
 typedef enum vit_status {
     VIT_OK = 0,
@@ -104,7 +104,8 @@ int vit_plan_query(const vit_plan *plan, vit_plan_info *info);
  * scripts can reach each kernel form (the library reads NO environment variables).  Keys:
  *   "forward_form"     banded plans: 0 by batch size | 1 one target per lane | 2 two targets per lane | 3 scan form |
  *                      4 wave form | 5 never the wave form
- *   "backtrace_form"   0 auto | 1 generic kernel | 2 whole-row kernels (no sparse fetch)
+ *   "backtrace_form"   0 auto | 1 generic kernel | 2 whole-row kernels (no sparse fetch) | 4 one (song, chunk) stream per LANE
+ *                      instead of per wavefront (banded plans, full history; up to 256 chunks per song; VIT_EUNSUPPORTED elsewhere)
  *   "dense_songs"      songs per workgroup of the dense kernel (0 auto); "dense_one_thread" 1 = one thread per target;
  *                      "dense_form" 0 = matrix-resident dense kernel where it applies (64 < S <= 368), 1 = always stream the matrix
  *   "step_form"        step-structured kernel: 0 four targets per lane, bands split over two waves | 1 one target per lane |
@@ -157,16 +158,28 @@ int vit_decode(const vit_plan *plan, const void *logE, int emis_dtype, int64_t B
 /* Forward pass only / back-trace only; used by bench.py to time the two kernels separately and to run the back-trace
  * of one batch on another stream.  vit_decode() == forward then backtrace.  vit_forward records, per plan and workspace
  * pointer, which kernel family filled the workspace and how its history rows are laid out; vit_backtrace reads that
- * record (its `algo` argument is ignored) and returns VIT_EINVAL when this workspace has no forward pass of the same
- * (B, T) on record (VIT_ENOFORWARD).  The caller orders the two calls (same stream, or an event).  A plan keeps the
- * records of the 64 workspaces most recently written; a failed vit_forward leaves none for its workspace.  The emission
- * tensor handed to vit_forward must stay valid and unchanged until vit_backtrace has run: a half history (wave form)
- * re-reads 32 emission values of every odd frame. */
+ * record (its `algo` argument is ignored) and returns VIT_ENOFORWARD when this workspace has no forward pass of the same
+ * (B, T) on record.  The caller orders the two calls (same stream, or an event).  A plan keeps the records of the 64
+ * workspaces most recently written; a failed vit_forward leaves none for its workspace.
+ *
+ * LIFETIME RULE: the emission tensor handed to vit_forward must stay valid and UNCHANGED until vit_backtrace has run -- a half
+ * history (wave form, "wave_history" 2) re-reads 32 emission values of every odd frame through the pointer vit_forward
+ * recorded.  vit_backtrace_checked() takes the emission pointer and storage type again and returns VIT_EINVAL when they are
+ * not the ones on record (a double-buffered caller that refilled or swapped its emission buffer between the two phases);
+ * the Python host always calls that form. */
 int vit_forward(const vit_plan *plan, const void *logE, int emis_dtype, int64_t B, int64_t T,
                 const int64_t *lengths, void *workspace, size_t workspace_bytes,
                 float *loglik, int algo, vit_stream stream);
 int vit_backtrace(const vit_plan *plan, int64_t B, int64_t T, const int64_t *lengths,
                   void *workspace, size_t workspace_bytes, int32_t *states, int algo, vit_stream stream);
+int vit_backtrace_checked(const vit_plan *plan, const void *logE, int emis_dtype, int64_t B, int64_t T,
+                          const int64_t *lengths, void *workspace, size_t workspace_bytes, int32_t *states,
+                          int algo, vit_stream stream);
+
+/* Which forward kernel family vit_forward() would launch for (plan, options, algo, batch size): 1 dense / step-structured,
+ * 2 banded with one song per workgroup, 3 banded with one song per wavefront; a negative vit_status when the algo is not
+ * available for this plan.  (The thresholds scale with the device's compute units; callers should ask, not guess.) */
+int vit_forward_family(const vit_plan *plan, int64_t B, int algo);
 
 /*
  * Bounded-workspace decode: the same result as vit_decode() with a workspace of about (T / segment_frames + segment_frames)
@@ -174,13 +187,33 @@ int vit_backtrace(const vit_plan *plan, int64_t B, int64_t T, const int64_t *len
  * tonet/for_paper.py:1852-1853; vit_decode keeps a history for the whole batch).  Pass 1 runs the forward recursion and keeps
  * one row per segment of segment_frames frames; pass 2 re-runs it segment by segment from the last to the first and
  * back-traces each.  Exact by construction; about twice the forward work.  Plans with the wave form only (vit_plan_info
- * reserved[2] bit 3; VIT_EUNSUPPORTED otherwise); 64 <= segment_frames.  The library does not record this call for
- * vit_backtrace().
+ * reserved[2] bit 3; VIT_EUNSUPPORTED otherwise); 64 <= segment_frames (values above T act like T).  Of the plan's options
+ * only "bt_fast_rows" and "wave_two" are honoured: the passes run the general wave kernel with a full history of the segment
+ * and the sparse back-trace ("wave_history", "wave_uniform", "backtrace_form", "bt_chunks" are ignored).  The library does
+ * not record this call for vit_backtrace().
  */
 size_t vit_workspace_bytes_checkpointed(const vit_plan *plan, int64_t B, int64_t T, int64_t segment_frames);
 int vit_decode_checkpointed(const vit_plan *plan, const void *logE, int emis_dtype, int64_t B, int64_t T,
                             const int64_t *lengths, void *workspace, size_t workspace_bytes, int32_t *states,
                             float *loglik, int64_t segment_frames, vit_stream stream);
+
+/*
+ * Packed (ragged) decode: B songs of DIFFERENT lengths without padding.  The reference decodes every recording whole with its
+ * own T (tonet/for_paper.py:2304-2309, one viterbi(logits) call per recording).
+ *   logE    : device, [offsets[B], S] C-order: the emission rows of song b are rows offsets[b] .. offsets[b+1]-1
+ *   offsets : HOST, [B+1] int64, offsets[0] = 0, strictly increasing (every song holds at least one frame)
+ *   states  : device, [offsets[B]] int32, packed like the emission rows
+ *   loglik  : device, [B] float32 or NULL
+ * Plans with the wave form only (vit_plan_info reserved[2] bit 3; VIT_EUNSUPPORTED otherwise): the forward pass runs
+ * min(B, 8 x compute units) wavefronts, each decoding a host-packed list of songs back to back (longest-first greedy bins by
+ * frame count), so a launch costs (total frames / wavefronts), not its longest song, and neither memory nor time is spent on
+ * padding; the back-trace cuts every song into chunks of about equal length.  The library builds the slot and chunk tables on
+ * the host from `offsets` and uploads them through a pinned staging buffer it owns (it waits for the previous call's upload
+ * before reusing it; otherwise no host synchronisation).  Bit-identical to vit_decode() of each song alone.
+ */
+size_t vit_workspace_bytes_packed(const vit_plan *plan, int64_t B, int64_t total_frames);
+int vit_decode_packed(const vit_plan *plan, const void *logE, int emis_dtype, int64_t B, const int64_t *offsets,
+                      void *workspace, size_t workspace_bytes, int32_t *states, float *loglik, vit_stream stream);
 
 /* Event counts of the last vit_backtrace() on this workspace (banded plans; all zero for the kernels that do not count):
  * *offset = byte offset, inside the workspace, of an int32 [B][*n_per_song] device array (valid once the back-trace has run

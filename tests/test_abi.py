@@ -37,7 +37,7 @@ def test_header_and_loader_agree(lib):
 
 def test_version_and_status_strings(lib):
     from viterbi_spl_amd import _lib
-    assert lib.vit_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.vit_abi_version() == _lib.ABI_VERSION == 4
     assert lib.vit_status_string(0) == b"ok"
     assert b"workspace" in lib.vit_status_string(-4)
 

@@ -1,0 +1,156 @@
+"""GPU parity tests of round 4, all through the C ABI: the packed (ragged) decode, the lane form of the back-trace, the checked
+back-trace phase.  Bar: states bit-exact, log-likelihood bit-equal against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import viterbi_oracle as vo
+from viterbi_spl_amd import ViterbiDecoder, _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _pack(E, lens):
+    """[B, T, S] + lengths -> packed [sum T_b, S], offsets."""
+    off = np.zeros(len(lens) + 1, np.int64)
+    off[1:] = np.cumsum(lens)
+    return torch.cat([E[b, :int(n)] for b, n in enumerate(lens)], dim=0).contiguous(), off
+
+
+def _unpack(states, off, T):
+    out = np.full((len(off) - 1, T), -1, np.int32)
+    for b in range(len(off) - 1):
+        out[b, :off[b + 1] - off[b]] = states[off[b]:off[b + 1]]
+    return out
+
+
+@pytest.mark.parametrize("name", ["tonet361", "msnet321"])
+def test_packed_decode_small(golden, dev, name):
+    """vit_decode_packed on a handful of songs (lengths 1, 2, odd, even, equal), fp32 and fp16 storage, every emission kind: the
+    states and log-likelihoods of the padded decode, i.e. of the oracle run on every song alone."""
+    A, pi = golden["params"][f"{name}_logA_T"], golden["params"][f"{name}_log_pi"]
+    dec = ViterbiDecoder(A, pi, dev)
+    assert dec.info["wave_ok"]
+    S, T = dec.S, 333
+    lens = np.array([T, 1, 2, 150, T - 1, 3, 64, 65, 66, 4, 5, T, 129, 1, 77], np.int64)
+    for kind, gen in (("peaks", synth.emissions_peaks), ("dense", synth.emissions_dense), ("ties", synth.emissions_ties)):
+        for dt in (torch.float32, torch.float16):
+            E = gen(len(lens), T, S, seed=9, device=dev, dtype=dt)
+            ref_s, ref_l = vo.decode_c(A, pi, E.float().cpu().numpy(), lengths=lens)
+            Ep, off = _pack(E, lens)
+            st, ll = dec.decode_packed(Ep, off, out_dtype=torch.int32)
+            assert np.array_equal(_unpack(st.cpu().numpy(), off, T), ref_s), (name, kind, dt)
+            assert np.array_equal(ll.cpu().numpy(), ref_l), (name, kind, dt)
+    with pytest.raises(ValueError):
+        dec.decode_packed(Ep, off[:-1])                      # offsets must end at the number of rows
+    with pytest.raises(ValueError):
+        dec.decode_packed(Ep, np.concatenate([off[:3], off[2:]]))   # an empty song
+
+
+def test_packed_decode_needs_the_wave_form(golden, dev):
+    dec = ViterbiDecoder(golden["params"]["dense97_logA_T"], golden["params"]["dense97_log_pi"], dev)
+    E = synth.emissions_dense(1, 10, 97, seed=1, device=dev)[0]
+    with pytest.raises(_lib.ViterbiHipError):
+        dec.decode_packed(E, [0, 10])
+
+
+def test_packed_decode_3000_ragged_songs(golden, dev):
+    """3072 recordings with lengths uniform in [T/4, T] (and a few of one or two frames) in one packed buffer: more songs than
+    forward slots (8 per compute unit), so every wavefront walks several songs back to back; every state and log-likelihood
+    equals the oracle's decode of that song alone."""
+    A, pi = golden["params"]["tonet361_logA_T"], golden["params"]["tonet361_log_pi"]
+    dec = ViterbiDecoder(A, pi, dev)
+    S, T, B, NU = 361, 1200, 3072, 96
+    rng = np.random.default_rng(31)
+    lens = rng.integers(T // 4, T + 1, B).astype(np.int64)
+    lens[[5, 777, 2048, B - 1]] = (1, 2, 1, T)
+    base = synth.emissions_peaks(NU, T, S, seed=77, device=dev)                 # songs repeat with period 96, lengths do not
+    off = np.zeros(B + 1, np.int64)
+    off[1:] = np.cumsum(lens)
+    Ep = torch.empty((int(off[-1]), S), dtype=torch.float32, device=dev)
+    for b in range(B):
+        Ep[off[b]:off[b + 1]] = base[b % NU, :lens[b]]
+    n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    assert B > 8 * n_cus or n_cus > 384, "the test wants more songs than slots"
+    st, ll = dec.decode_packed(Ep, off, out_dtype=torch.int32)
+    st, ll = st.cpu().numpy(), ll.cpu().numpy()
+    base_h = base.cpu().numpy()
+    for u in range(NU):                                                          # the oracle, once per distinct (song, length)
+        idx = np.arange(u, B, NU)
+        Eu = np.broadcast_to(base_h[u], (len(idx), T, S))
+        rs, rl = vo.decode_c(A, pi, np.ascontiguousarray(Eu), lengths=lens[idx])
+        for k, b in enumerate(idx):
+            assert np.array_equal(st[off[b]:off[b + 1]], rs[k, :lens[b]]), (b, int(lens[b]))
+            assert ll[b] == rl[k], b
+    st2, ll2 = dec.decode_packed(Ep, off, out_dtype=torch.int32)                 # a second run returns identical bytes
+    assert np.array_equal(st2.cpu().numpy(), st) and np.array_equal(ll2.cpu().numpy(), ll)
+
+
+@pytest.mark.parametrize("name", ["tonet361", "msnet321", "jdc722", "imm722w"])
+def test_lane_form_of_the_backtrace(golden, dev, name):
+    """backtrace_form 4: one (song, chunk) stream per lane (backtrace_lane.hip), up to 256 chunks per song, forced bad guesses
+    (zero warm-up: the verify / repair passes decide), ragged lengths down to one frame, behind both forward forms."""
+    A, pi = golden["params"][f"{name}_logA_T"], golden["params"][f"{name}_log_pi"]
+    dec = ViterbiDecoder(A, pi, dev)
+    S, T = dec.S, 701
+    lens = torch.tensor([T, 1, 2, 150, T - 1, 3, 64, 65, 66, 4, 5], dtype=torch.int64, device=dev)
+    for kind, gen in (("peaks", synth.emissions_peaks), ("dense", synth.emissions_dense), ("ties", synth.emissions_ties)):
+        for dt in ((torch.float32, torch.float16) if S < 400 else (torch.float32,)):
+            E = gen(11, T, S, seed=5, device=dev, dtype=dt)
+            ref_s, ref_l = vo.decode_c(A, pi, E.float().cpu().numpy(), lengths=lens.cpu().numpy())
+            for algo in (("wave", "group") if dec.info["wave_ok"] else ("group",)):
+                for chunks, warm in ((0, -1), (7, 0), (1, -1), (64, 0), (200, 3), (256, -1)):
+                    dec.set_option("reset", 0)
+                    dec.set_option("backtrace_form", 4)
+                    dec.set_option("bt_chunks", chunks)
+                    dec.set_option("bt_warm", warm)
+                    st, ll = dec.decode(E, lengths=lens, algo=algo, out_dtype=torch.int32)
+                    assert np.array_equal(st.cpu().numpy(), ref_s), (name, kind, dt, algo, chunks, warm)
+                    assert np.array_equal(ll.cpu().numpy(), ref_l), (name, kind, dt, algo, chunks, warm)
+    dec.set_option("reset", 0)
+    dense = ViterbiDecoder(golden["params"]["dense97_logA_T"], golden["params"]["dense97_log_pi"], dev)
+    dense.set_option("backtrace_form", 4)
+    with pytest.raises(_lib.ViterbiHipError):                                    # unstructured matrix: refused loudly, no silent other kernel
+        dense.decode(synth.emissions_dense(1, 20, 97, seed=1, device=dev))
+
+
+def test_backtrace_phase_refuses_another_emission_tensor(golden, dev):
+    """The split form's lifetime rule: the back-trace phase hands the emission pointer to the library
+    (vit_backtrace_checked), which refuses a tensor other than the one the forward pass decoded -- with the half history it
+    would read the odd frames' emissions from it."""
+    A, pi = golden["params"]["tonet361_logA_T"], golden["params"]["tonet361_log_pi"]
+    dec = ViterbiDecoder(A, pi, dev)
+    E = synth.emissions_peaks(3, 120, 361, seed=2, device=dev)
+    E2 = E.clone()
+    st = torch.empty((3, 120), dtype=torch.int32, device=dev)
+    ref_s, _ = vo.decode_c(A, pi, E.cpu().numpy())
+    for hist in (1, 2):
+        dec.set_option("wave_history", hist)
+        dec.decode_into(E, st, None, algo="wave", phase="forward")
+        with pytest.raises(_lib.ViterbiHipError, match="invalid argument"):
+            dec.decode_into(E2, st, None, algo="wave", phase="backtrace")        # same values, another buffer
+        with pytest.raises(_lib.ViterbiHipError, match="invalid argument"):
+            dec.decode_into(E.half(), st, None, algo="wave", phase="backtrace")  # another storage type
+        dec.decode_into(E, st, None, algo="wave", phase="backtrace")
+        assert np.array_equal(st.cpu().numpy(), ref_s), hist
+    dec.set_option("reset", 0)
+
+
+def test_forward_family_query(golden, dev):
+    """vit_forward_family: what bench.py asks instead of guessing the library's batch-size thresholds."""
+    dec = ViterbiDecoder(golden["params"]["tonet361_logA_T"], golden["params"]["tonet361_log_pi"], dev)
+    n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    assert dec.forward_family(1, "banded") == "group" and dec.forward_family(2 * n_cus, "banded") == "group"
+    assert dec.forward_family(2 * n_cus + 1, "banded") == "wave" and dec.forward_family(1, "wave") == "wave"
+    assert dec.forward_family(4096, "dense") == "dense"
+    dense = ViterbiDecoder(golden["params"]["dense97_logA_T"], golden["params"]["dense97_log_pi"], dev)
+    assert dense.forward_family(64, "auto") == "dense"
+    with pytest.raises(_lib.ViterbiHipError):
+        dense.forward_family(64, "wave")

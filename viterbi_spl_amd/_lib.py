@@ -21,8 +21,9 @@ EXPORTS = (
     "vit_plan_query", "vit_plan_image_bytes", "vit_plan_upload", "vit_workspace_bytes", "vit_decode",
     "vit_forward", "vit_backtrace", "vit_voicing_map", "vit_obs_shaun", "vit_obs_softmax", "vit_obs_softmax_scaled", "vit_plan_set_option", "vit_snippets_append", "vit_voicing_notes",
     "vit_workspace_bytes_for", "vit_debug_scan", "vit_backtrace_counters", "vit_workspace_bytes_checkpointed", "vit_decode_checkpointed",
+    "vit_backtrace_checked", "vit_forward_family", "vit_workspace_bytes_packed", "vit_decode_packed",
 )
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class PlanInfo(ctypes.Structure):
@@ -92,6 +93,14 @@ def load() -> ctypes.CDLL:
     lib.vit_forward.argtypes = [vp, vp, i32, i64, i64, vp, vp, sz, vp, i32, vp]
     lib.vit_backtrace.restype = i32
     lib.vit_backtrace.argtypes = [vp, i64, i64, vp, vp, sz, vp, i32, vp]
+    lib.vit_backtrace_checked.restype = i32
+    lib.vit_backtrace_checked.argtypes = [vp, vp, i32, i64, i64, vp, vp, sz, vp, i32, vp]
+    lib.vit_workspace_bytes_packed.restype = sz
+    lib.vit_workspace_bytes_packed.argtypes = [vp, i64, i64]
+    lib.vit_decode_packed.restype = i32
+    lib.vit_decode_packed.argtypes = [vp, vp, i32, i64, vp, vp, sz, vp, vp, vp]
+    lib.vit_forward_family.restype = i32
+    lib.vit_forward_family.argtypes = [vp, i64, i32]
     lib.vit_voicing_map.restype = i32
     lib.vit_voicing_map.argtypes = [vp, i64, i32, vp, vp, vp]
     f64 = ctypes.c_double

@@ -1,9 +1,12 @@
 // capi.hip -- extern "C" entry points declared in include/viterbi_hip.h.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
+#include <queue>
 #include <new>
 #include <utility>
 #include <vector>
@@ -18,7 +21,8 @@
 struct Tuning {
     int forward_form = 0;      // banded plans: 0 by batch size | 1 one target per lane | 2 two targets per lane | 3 scan form
                                //               | 4 wave form (one song per wavefront) | 5 never the wave form
-    int backtrace_form = 0;    // 0 auto | 1 generic (lazy) kernel | 2 whole-row kernels
+    int backtrace_form = 0;    // 0 auto (sparse fetch, one stream per wavefront, where it applies) | 1 generic (lazy) kernel | 2 whole-row kernels |
+                               // 4 one stream per LANE (backtrace_lane.hip; VIT_EUNSUPPORTED where it does not apply)
     int dense_songs = 0;       // songs per workgroup of the dense kernel (0 = by batch size)
     int dense_one_thread = 0;  // 1: one thread per target in the dense kernel even where two fit
     int dense_form = 0;        // 0: matrix-resident dense kernel where it applies (64 < S <= 368) | 1: always the streaming kernel
@@ -59,6 +63,14 @@ struct vit_plan {
     Tuning tune;
     mutable std::mutex mu;
     mutable std::vector<FwdStamp> stamps;   // most recent first, at most kMaxStamps
+    // vit_decode_packed: pinned host staging of the slot / chunk tables, and the event of the copy that last read it
+    mutable void* pk_host = nullptr;
+    mutable size_t pk_host_bytes = 0;
+    mutable hipEvent_t pk_event = nullptr;
+    ~vit_plan() {
+        if (pk_event) (void)hipEventDestroy(pk_event);
+        if (pk_host) (void)hipHostFree(pk_host);
+    }
 };
 
 namespace {
@@ -103,7 +115,7 @@ int hip_fail(hipError_t e) {
 }
 
 struct WsLayout {
-    size_t off_hist, off_fmax, off_last, off_entry, bytes;
+    size_t off_hist, off_fmax, off_cnt, off_mask, off_last, off_entry, bytes;
 };
 
 // history floats per song: `rows` rows of `stride` floats
@@ -111,9 +123,11 @@ WsLayout ws_layout_hist(int64_t B, size_t rows, size_t stride) {
     WsLayout w;
     w.off_hist = 0;
     w.off_fmax = align256((size_t)B * rows * stride * sizeof(float));
-    w.off_last = w.off_fmax + align256((size_t)B * 64 * sizeof(float));   // timing-experiment scratch
+    w.off_cnt = w.off_fmax + align256((size_t)B * 64 * sizeof(float));    // (off_fmax: timing-experiment scratch of the forward kernels)
+    w.off_mask = w.off_cnt + align256((size_t)B * vit::kBtCounters * sizeof(int32_t));   // the back-trace's event counters, then its chunk flags:
+    w.off_last = w.off_mask + align256((size_t)B * vit::kLaneMaskWords * sizeof(uint32_t));   // one memset covers both
     w.off_entry = w.off_last + align256((size_t)B * sizeof(int32_t));
-    w.bytes = w.off_entry + align256((size_t)B * vit::kBtMaxChunks * sizeof(int32_t));
+    w.bytes = w.off_entry + align256((size_t)B * vit::kLaneMaxChunks * sizeof(int32_t));
     return w;
 }
 // the layout that covers every forward kernel of the plan (vit_workspace_bytes)
@@ -401,6 +415,8 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
     st.col0 = 0;
     st.mcol = plan->S;
     st.have_fmax = family == 2 ? 1 : 0;
+    st.logE = logE;
+    st.e_f16 = emis_dtype == VIT_F16 ? 1 : 0;
     hipError_t e;
     if (family == 3) {
         st.SD = vit::wave_hist_stride(plan->bp.wave_npl);
@@ -409,8 +425,6 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
         st.xcol0 = 1;
         st.have_fmax = 1;
         st.half = half ? 1 : 0;
-        st.logE = logE;
-        st.e_f16 = emis_dtype == VIT_F16 ? 1 : 0;
         e = vit::launch_wave(a, emis_dtype == VIT_F16, (hipStream_t)stream);
     } else if (family == 2) {
         e = vit::launch_banded(a, emis_dtype == VIT_F16, (hipStream_t)stream);
@@ -463,15 +477,37 @@ static void bt_args_from_plan(const vit_plan* plan, vit::BtArgs& b) {
     b.off_rowc = plan->L.off_rowc;
 }
 
+int vit_forward_family(const vit_plan* plan, int64_t B, int algo) {
+    if (!plan || B < 0) return VIT_EINVAL;
+    return resolve_family(plan, algo, B);
+}
+
+static int backtrace_impl(const vit_plan* plan, const void* logE, int emis_dtype, bool check_e, int64_t B, int64_t T, const int64_t* lengths,
+                          void* workspace, size_t workspace_bytes, int32_t* states, vit_stream stream);
+
 int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* lengths, void* workspace,
                   size_t workspace_bytes, int32_t* states, int algo, vit_stream stream) {
+    (void)algo;   // kept for ABI compatibility: the layout comes from what vit_forward recorded for this workspace
+    return backtrace_impl(plan, nullptr, 0, false, B, T, lengths, workspace, workspace_bytes, states, stream);
+}
+
+int vit_backtrace_checked(const vit_plan* plan, const void* logE, int emis_dtype, int64_t B, int64_t T, const int64_t* lengths,
+                          void* workspace, size_t workspace_bytes, int32_t* states, int algo, vit_stream stream) {
+    (void)algo;
+    if (!logE || (emis_dtype != VIT_F32 && emis_dtype != VIT_F16)) return VIT_EINVAL;
+    return backtrace_impl(plan, logE, emis_dtype, true, B, T, lengths, workspace, workspace_bytes, states, stream);
+}
+
+static int backtrace_impl(const vit_plan* plan, const void* logE, int emis_dtype, bool check_e, int64_t B, int64_t T, const int64_t* lengths,
+                          void* workspace, size_t workspace_bytes, int32_t* states, vit_stream stream) {
     int rc = check_common(plan, B, T, workspace);
     if (rc != VIT_OK) return rc;
     if (!states) return VIT_EINVAL;
-    (void)algo;   // kept for ABI compatibility: the layout comes from what vit_forward recorded for this workspace
     if (B == 0) return VIT_OK;
     FwdStamp st;
     if (!stamp_get(plan, workspace, &st) || st.B != B || st.T != T) return VIT_ENOFORWARD;   // no matching vit_forward
+    // the emission tensor must be the one the forward pass decoded (a half history reads it again through the recorded pointer)
+    if (check_e && (st.logE != logE || st.e_f16 != (emis_dtype == VIT_F16 ? 1 : 0))) return VIT_EINVAL;
     const Tuning& tn = plan->tune;
     const WsLayout w = st.half ? ws_layout_hist(B, (size_t)((T + 1) / 2), (size_t)st.SD) : ws_layout_hist(B, (size_t)T, (size_t)st.SD);
     if (workspace_bytes < w.bytes) return VIT_EWORKSPACE;
@@ -493,10 +529,10 @@ int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* len
     b.states_stride = T;
     if (st.family == 3 && !(b.banded && b.n_dense == 0)) return VIT_EINVAL;   // (cannot happen: wave_ok implies both)
     b.hist_rows = T;
-    b.counters = nullptr;
-    if ((size_t)B * vit::kBtCounters * sizeof(int32_t) <= align256((size_t)B * 64 * sizeof(float))) {
-        b.counters = reinterpret_cast<int32_t*>(ws + w.off_fmax);     // the per-song scratch: event counts of this back-trace
-        hipError_t ez = hipMemsetAsync(b.counters, 0, (size_t)B * vit::kBtCounters * sizeof(int32_t), (hipStream_t)stream);
+    b.counters = reinterpret_cast<int32_t*>(ws + w.off_cnt);          // event counts of this back-trace, chunk flags of the lane form
+    b.mask = reinterpret_cast<uint32_t*>(ws + w.off_mask);
+    {
+        hipError_t ez = hipMemsetAsync(ws + w.off_cnt, 0, w.off_last - w.off_cnt, (hipStream_t)stream);
         if (ez != hipSuccess) return hip_fail(ez);
     }
     if (st.half) {
@@ -515,6 +551,14 @@ int vit_backtrace(const vit_plan* plan, int64_t B, int64_t T, const int64_t* len
         hipError_t eh = vit::launch_backtrace_half(b, (hipStream_t)stream);
         return eh == hipSuccess ? VIT_OK : hip_fail(eh);
     }
+    if (b.bt_form == 4) {                                             // one (song, chunk) stream per lane
+        if (!vit::lane_backtrace_applies(b)) return VIT_EUNSUPPORTED;
+        b.warm = tn.bt_warm >= 0 ? tn.bt_warm : vit::kBtWarmSparse;
+        b.chunks = vit::lane_backtrace_chunks(B, (int)T, plan->n_cus, b.warm);
+        if (tn.bt_chunks >= 1 && tn.bt_chunks <= vit::kLaneMaxChunks) b.chunks = tn.bt_chunks;
+        hipError_t el = vit::launch_backtrace_lane(b, (hipStream_t)stream);
+        return el == hipSuccess ? VIT_OK : hip_fail(el);
+    }
     const bool sparse = b.bt_form == 0 && vit::sparse_backtrace_applies(b);
     b.chunks = sparse ? vit::sparse_backtrace_chunks(B, (int)T, plan->n_cus) : vit::backtrace_chunks(B, (int)T);
     b.warm = sparse ? vit::kBtWarmSparse : vit::kBtWarm;
@@ -530,7 +574,7 @@ int vit_backtrace_counters(const vit_plan* plan, int64_t B, int64_t T, const voi
     FwdStamp st;
     if (!stamp_get(plan, workspace, &st) || st.B != B || st.T != T) return VIT_ENOFORWARD;
     const WsLayout w = st.half ? ws_layout_hist(B, (size_t)((T + 1) / 2), (size_t)st.SD) : ws_layout_hist(B, (size_t)T, (size_t)st.SD);
-    *offset = w.off_fmax;
+    *offset = w.off_cnt;
     *n_per_song = vit::kBtCounters;
     return VIT_OK;
 }
@@ -560,6 +604,7 @@ struct CkLayout {
 };
 CkLayout ck_layout(const vit_plan* p, int64_t B, int64_t T, int64_t K) {
     CkLayout c;
+    K = K > T ? T : K;                                                           // (a segment longer than the songs: one segment of T frames)
     const size_t sd = (size_t)vit::wave_hist_stride(p->bp.wave_npl) * sizeof(float);
     c.nseg = (T + K - 1) / K;
     c.off_ckpt = 0;                                                              // [B][nseg] rows: nseg - 1 checkpoints + the scratch row
@@ -588,8 +633,8 @@ int vit_decode_checkpointed(const vit_plan* plan, const void* logE, int emis_dty
     if (rc != VIT_OK) return rc;
     if (!logE || !states) return VIT_EINVAL;
     if (emis_dtype != VIT_F32 && emis_dtype != VIT_F16) return VIT_EINVAL;
-    const int64_t K = segment_frames;
-    if (!ck_supported(plan, K)) return K < 64 || K > (int64_t)1 << 24 ? VIT_EINVAL : VIT_EUNSUPPORTED;
+    if (!ck_supported(plan, segment_frames)) return segment_frames < 64 || segment_frames > (int64_t)1 << 24 ? VIT_EINVAL : VIT_EUNSUPPORTED;
+    const int64_t K = segment_frames > T ? T : segment_frames;
     const CkLayout c = ck_layout(plan, B, T, K);
     if (workspace_bytes < c.bytes) return VIT_EWORKSPACE;
     if (B == 0) return VIT_OK;
@@ -668,6 +713,197 @@ int vit_decode_checkpointed(const vit_plan* plan, const void* logE, int emis_dty
         if (e != hipSuccess) return hip_fail(e);
     }
     return VIT_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Packed (ragged) decode.  The reference decodes every recording whole with its own T (tonet/for_paper.py:2304-2309); a padded
+// [B, T_max, S] tensor wastes memory on the padding and a launch with one wavefront per song costs its LONGEST song.  Here the
+// emissions of B songs are one [sum T_b, S] buffer, the history and the states are packed the same way, and the forward pass
+// runs n_slots <= 8 waves per CU, each walking a host-packed list of songs back to back (longest-first greedy bins by frames:
+// the rule of sharded.shard_by_length), so that every wave carries about the same number of frames.  The back-trace cuts every
+// song into chunks of about equal length (total frames / resident waves), one wave per chunk.
+namespace {
+
+struct PkLayout {
+    int64_t n_slots, max_waves;
+    size_t off_hist, off_cnt, off_mask, off_last, off_entry, off_offsets, off_slot_begin, off_slot_songs, off_wave_song, off_chunk_base, bytes;
+    size_t tables_bytes;      // offsets .. chunk_base: one contiguous upload
+};
+inline int64_t pk_slots(const vit_plan* p, int64_t B) { const int64_t cap = 8 * (int64_t)p->n_cus; return B < cap ? B : cap; }
+inline int64_t pk_max_waves(const vit_plan* p, int64_t B) { return B + 16 * (int64_t)p->n_cus; }
+PkLayout pk_layout(const vit_plan* p, int64_t B, int64_t N) {
+    PkLayout k;
+    const size_t sd = (size_t)vit::wave_hist_stride(p->bp.wave_npl) * sizeof(float);
+    k.n_slots = pk_slots(p, B);
+    k.max_waves = pk_max_waves(p, B);
+    k.off_hist = 0;
+    k.off_cnt = align256((size_t)N * sd);
+    k.off_mask = k.off_cnt + align256((size_t)B * vit::kBtCounters * sizeof(int32_t));
+    k.off_last = k.off_mask + align256((size_t)B * vit::kLaneMaskWords * sizeof(uint32_t));
+    k.off_entry = k.off_last + align256((size_t)B * sizeof(int32_t));
+    k.off_offsets = k.off_entry + align256((size_t)k.max_waves * sizeof(int32_t));
+    k.off_slot_begin = k.off_offsets + align256((size_t)(B + 1) * sizeof(int64_t));
+    k.off_slot_songs = k.off_slot_begin + align256((size_t)(k.n_slots + 1) * sizeof(int32_t));
+    k.off_wave_song = k.off_slot_songs + align256((size_t)B * sizeof(int32_t));
+    k.off_chunk_base = k.off_wave_song + align256((size_t)k.max_waves * sizeof(int32_t));
+    k.bytes = k.off_chunk_base + align256((size_t)(B + 1) * sizeof(int32_t));
+    k.tables_bytes = k.bytes - k.off_offsets;
+    return k;
+}
+
+}  // namespace
+
+size_t vit_workspace_bytes_packed(const vit_plan* plan, int64_t B, int64_t total_frames) {
+    if (!plan || B < 0 || total_frames < 0 || !(plan->bp.ok && plan->bp.wave_ok)) return 0;
+    return pk_layout(plan, B, total_frames).bytes;
+}
+
+int vit_decode_packed(const vit_plan* plan, const void* logE, int emis_dtype, int64_t B, const int64_t* offsets, void* workspace,
+                      size_t workspace_bytes, int32_t* states, float* loglik, vit_stream stream) {
+    if (!plan || !workspace || !offsets) return VIT_EINVAL;
+    if (B < 0 || B > (int64_t)1 << 30) return VIT_EINVAL;
+    if (!plan->dev_image) return VIT_ENOTUPLOADED;
+    if (((uintptr_t)workspace & 255) != 0) return VIT_EINVAL;
+    if (emis_dtype != VIT_F32 && emis_dtype != VIT_F16) return VIT_EINVAL;
+    if (!(plan->bp.ok && plan->bp.wave_ok)) return VIT_EUNSUPPORTED;
+    if (offsets[0] != 0) return VIT_EINVAL;
+    for (int64_t b = 0; b < B; ++b) {
+        const int64_t tb = offsets[b + 1] - offsets[b];
+        if (tb < 1 || tb > (int64_t)1 << 30) return VIT_EINVAL;      // every song holds at least one frame
+    }
+    const int64_t N = offsets[B];
+    if (B == 0) return VIT_OK;
+    if (!logE || !states) return VIT_EINVAL;
+    const PkLayout k = pk_layout(plan, B, N);
+    if (workspace_bytes < k.bytes) return VIT_EWORKSPACE;
+    stamp_erase(plan, workspace);
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t* ws = static_cast<uint8_t*>(workspace);
+
+    // ---- host tables in the plan's pinned staging buffer (the previous call's upload must have read it)
+    {
+        std::lock_guard<std::mutex> g(plan->mu);
+        if (plan->pk_event) { hipError_t ew = hipEventSynchronize(plan->pk_event); if (ew != hipSuccess) return hip_fail(ew); }
+        else { hipError_t ec = hipEventCreateWithFlags(&plan->pk_event, hipEventDisableTiming); if (ec != hipSuccess) return hip_fail(ec); }
+        if (plan->pk_host_bytes < k.tables_bytes) {
+            if (plan->pk_host) (void)hipHostFree(plan->pk_host);
+            plan->pk_host = nullptr;
+            plan->pk_host_bytes = 0;
+            hipError_t ea = hipHostMalloc(&plan->pk_host, k.tables_bytes, hipHostMallocDefault);
+            if (ea != hipSuccess) return hip_fail(ea);
+            plan->pk_host_bytes = k.tables_bytes;
+        }
+    }
+    uint8_t* hb = static_cast<uint8_t*>(plan->pk_host);
+    std::memset(hb, 0, k.tables_bytes);
+    int64_t* h_off = reinterpret_cast<int64_t*>(hb + (k.off_offsets - k.off_offsets));
+    int32_t* h_slot_begin = reinterpret_cast<int32_t*>(hb + (k.off_slot_begin - k.off_offsets));
+    int32_t* h_slot_songs = reinterpret_cast<int32_t*>(hb + (k.off_slot_songs - k.off_offsets));
+    int32_t* h_wave_song = reinterpret_cast<int32_t*>(hb + (k.off_wave_song - k.off_offsets));
+    int32_t* h_chunk_base = reinterpret_cast<int32_t*>(hb + (k.off_chunk_base - k.off_offsets));
+    std::memcpy(h_off, offsets, (size_t)(B + 1) * sizeof(int64_t));
+    int64_t max_chunks = 1;
+    try {
+        // forward slots: longest song first into the slot with the fewest frames (ties: fewest songs, lowest slot)
+        std::vector<int32_t> order((size_t)B);
+        for (int64_t b = 0; b < B; ++b) order[(size_t)b] = (int32_t)b;
+        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return offsets[x + 1] - offsets[x] > offsets[y + 1] - offsets[y]; });
+        typedef std::pair<std::pair<int64_t, int32_t>, int32_t> Load;       // ((frames, songs), slot)
+        std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+        for (int32_t sl = 0; sl < (int32_t)k.n_slots; ++sl) heap.push(Load{{0, 0}, sl});
+        std::vector<int32_t> slot_of((size_t)B);
+        std::vector<int32_t> count((size_t)k.n_slots, 0);
+        for (int32_t sng : order) {
+            Load l = heap.top();
+            heap.pop();
+            slot_of[(size_t)sng] = l.second;
+            ++count[(size_t)l.second];
+            l.first.first += offsets[sng + 1] - offsets[sng];
+            ++l.first.second;
+            heap.push(l);
+        }
+        h_slot_begin[0] = 0;
+        for (int64_t sl = 0; sl < k.n_slots; ++sl) h_slot_begin[sl + 1] = h_slot_begin[sl] + count[(size_t)sl];
+        std::vector<int32_t> fill(h_slot_begin, h_slot_begin + k.n_slots);
+        for (int32_t sng : order) h_slot_songs[fill[(size_t)slot_of[(size_t)sng]]++] = sng;     // a slot walks its songs longest first
+        // back-trace chunks: about (total frames / resident waves) frames each, never shorter than eight warm-ups
+        const int64_t resident = 16 * (int64_t)plan->n_cus;
+        int64_t cf = (N + resident - 1) / resident;
+        cf = cf < 8 * vit::kBtWarmSparse ? 8 * vit::kBtWarmSparse : cf;
+        int64_t w = 0;
+        for (int64_t b = 0; b < B; ++b) {
+            const int64_t tb = offsets[b + 1] - offsets[b];
+            int64_t c = (tb + cf / 2) / cf;
+            c = c < 1 ? 1 : (c > vit::kBtMaxChunks ? vit::kBtMaxChunks : c);
+            h_chunk_base[b] = (int32_t)w;
+            for (int64_t q = 0; q < c; ++q) h_wave_song[w + q] = (int32_t)b;
+            w += c;
+            max_chunks = c > max_chunks ? c : max_chunks;
+        }
+        h_chunk_base[B] = (int32_t)w;
+        if (w > k.max_waves) return VIT_EINVAL;      // (cannot happen: sum of round(T_b / cf) <= B + N / cf <= B + 16 n_cus)
+    } catch (const std::bad_alloc&) {
+        return VIT_ENOMEM;
+    }
+    const int n_waves = h_chunk_base[B];
+    hipError_t e = hipMemcpyAsync(ws + k.off_offsets, hb, k.tables_bytes, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return hip_fail(e);
+    e = hipEventRecord(plan->pk_event, st);
+    if (e != hipSuccess) return hip_fail(e);
+    e = hipMemsetAsync(ws + k.off_cnt, 0, k.off_last - k.off_cnt, st);
+    if (e != hipSuccess) return hip_fail(e);
+
+    // ---- forward: one wave per slot
+    vit::FwdArgs a{};
+    fwd_args_from_plan(plan, a);
+    a.logE = logE;
+    a.lengths = nullptr;
+    a.hist = reinterpret_cast<float*>(ws + k.off_hist);
+    a.fmax = nullptr;
+    a.last_state = reinterpret_cast<int32_t*>(ws + k.off_last);
+    a.loglik = loglik;
+    a.B = B;
+    a.T = 1;                      // (unused by the packed kernel: a song's rows come from the offsets)
+    a.hist_rows = 0;
+    a.t_begin = 0;
+    a.t_end = 1;
+    a.offsets = reinterpret_cast<const int64_t*>(ws + k.off_offsets);
+    a.n_slots = (int)k.n_slots;
+    a.slot_begin = reinterpret_cast<const int32_t*>(ws + k.off_slot_begin);
+    a.slot_songs = reinterpret_cast<const int32_t*>(ws + k.off_slot_songs);
+    e = vit::launch_wave(a, emis_dtype == VIT_F16, st);
+    if (e != hipSuccess) return hip_fail(e);
+
+    // ---- back-trace: one wave per (song, chunk)
+    vit::BtArgs b{};
+    bt_args_from_plan(plan, b);
+    b.SD = vit::wave_hist_stride(plan->bp.wave_npl);
+    b.col0 = b.SD - plan->S;
+    b.mcol = 0;
+    b.xcol0 = 1;
+    b.have_fmax = 1;
+    b.hist = reinterpret_cast<const float*>(ws + k.off_hist);
+    b.hist_rows = 0;
+    b.last_state = reinterpret_cast<const int32_t*>(ws + k.off_last);
+    b.lengths = nullptr;
+    b.states = states;
+    b.states_stride = 0;
+    b.entry = reinterpret_cast<int32_t*>(ws + k.off_entry);
+    b.B = B;
+    b.T = 1;
+    b.counters = reinterpret_cast<int32_t*>(ws + k.off_cnt);
+    b.mask = reinterpret_cast<uint32_t*>(ws + k.off_mask);
+    b.offsets = a.offsets;
+    b.wave_song = reinterpret_cast<const int32_t*>(ws + k.off_wave_song);
+    b.chunk_base = reinterpret_cast<const int32_t*>(ws + k.off_chunk_base);
+    b.n_waves = n_waves;
+    b.chunks = (int)max_chunks;
+    b.warm = plan->tune.bt_warm >= 0 ? plan->tune.bt_warm : vit::kBtWarmSparse;
+    b.bt_form = 0;
+    if (!vit::sparse_backtrace_applies(b)) return VIT_EUNSUPPORTED;
+    e = vit::launch_backtrace_sparse(b, st);
+    return e == hipSuccess ? VIT_OK : hip_fail(e);
 }
 
 int vit_voicing_map(const int32_t* states, int64_t n, int32_t n_bins, uint8_t* voiced, int32_t* bins,

@@ -69,6 +69,12 @@ struct FwdArgs {
     int ckpt_every, t_begin, t_end;
     const float* init_rows;
     int64_t init_stride;    // floats from one song's init row to the next
+    // packed batch (vit_decode_packed; wave form): emission rows of song b are rows offsets[b] .. offsets[b+1]-1 of logE, its history rows
+    // sit at the same offsets; wave w (slot w < n_slots) decodes songs slot_songs[slot_begin[w] .. slot_begin[w+1]) back to back
+    const int64_t* offsets; // device [B+1], or null
+    int n_slots;
+    const int32_t* slot_begin;   // device [n_slots + 1]
+    const int32_t* slot_songs;   // device [B]
     int win_shift;          // 0..3: delta is stored shifted by this many floats in LDS so that the window starts of a
                             // 16-lane group are 16-byte aligned in the SAME copy order (bank-conflict-free b128 reads)
 };
@@ -107,6 +113,14 @@ struct BtArgs {
     int no_fast_rows;       // sparse / half back-trace: 1 = every row through the general code (vit_plan_set_option "bt_fast_rows" 1; tests)
     int skip_nonpositive;   // sparse kernel: a song whose lengths[] entry is < 1 is skipped (segments; vit_decode clamps to 1 instead)
     int32_t* counters;      // [B][kBtCounters] per-song event counts of the sparse / half / half-wave kernels (zeroed by vit_backtrace)
+    // packed batch (vit_decode_packed): history rows / states of song b at offsets[b] (its length: offsets[b+1] - offsets[b]); the
+    // speculative pass runs one wave per entry of wave_song (song b owns waves chunk_base[b] .. chunk_base[b+1]-1 = its chunks;
+    // chunk entries are indexed the same way)
+    const int64_t* offsets; // device [B+1], or null
+    const int32_t* wave_song;    // device [n_waves]
+    const int32_t* chunk_base;   // device [B+1]
+    int n_waves;
+    uint32_t* mask;         // [B][kLaneMaskWords] lane form: bit c = chunk c assumed the wrong state at its upper boundary (zeroed by vit_backtrace)
 };
 
 hipError_t launch_dense(const FwdArgs& a, int songs_per_group, bool f16, hipStream_t st);
@@ -129,6 +143,10 @@ hipError_t launch_backtrace_sparse(const BtArgs& a, hipStream_t st, int phases =
 bool half_backtrace_applies(const BtArgs& a);
 hipError_t launch_backtrace_half(const BtArgs& a, hipStream_t st, int phases = 3);
 int sparse_backtrace_chunks(int64_t B, int T, int n_cus);
+// backtrace_lane.hip: one (song, chunk) stream per LANE (banded plans, full history): ~130 wave instructions per 64 decisions
+bool lane_backtrace_applies(const BtArgs& a);
+hipError_t launch_backtrace_lane(const BtArgs& a, hipStream_t st, int phases = 3);
+int lane_backtrace_chunks(int64_t B, int T, int n_cus, int warm);
 hipError_t launch_voicing_map(const int32_t* states, int64_t n, int32_t n_bins, uint8_t* voiced, int32_t* bins,
                               hipStream_t st);
 hipError_t launch_scan_selftest(const float* vals, int n_waves, int mode, float* out_v, int32_t* out_i,
@@ -144,7 +162,9 @@ hipError_t launch_voicing_notes(const int32_t* states, int64_t n, int32_t n_bins
 int backtrace_tile_rows(int SD);
 constexpr int kBtWarm = 128;       // warm-up frames of a speculative chunk (survivor paths coalesce within tens of frames)
 constexpr int kBtWarmSparse = 64;  // the sparse kernel runs many short chunks: a shorter warm-up (a wrong guess only costs a repair)
-constexpr int kBtMaxChunks = 32;
+constexpr int kBtMaxChunks = 32;    // one stream per wavefront (sparse / half / whole-row kernels)
+constexpr int kLaneMaxChunks = 256; // one stream per lane (backtrace_lane.hip); the workspace holds [B][kLaneMaxChunks] chunk entries
+constexpr int kLaneMaskWords = kLaneMaxChunks / 32;
 // per-song event counters (include/viterbi_hip.h vit_backtrace_counters): tiles fetched, span misses, whole-row evaluations
 // (bound failures), of those: odd rows rebuilt in full, chunks repaired, frames rewritten by repairs
 constexpr int kBtCounters = 16;

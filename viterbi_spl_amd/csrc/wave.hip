@@ -167,17 +167,11 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
     static_assert(UV == 0 || NX == 1, "last-state / uniform-lane forms: one extra column");
     static_assert(UV < 2 || NPL == 6, "uniform-lane forms: six states per lane");
     constexpr bool U5 = UV == 2, U3 = UV == 3;
-    const int S = a.S, T = a.T;
+    constexpr bool PK = HM == 7;               // packed batch: this wave is a SLOT that walks a list of songs back to back
+    const int S = a.S;
     const int lane = threadIdx.x & 63;
-    const int song = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (song >= a.B) return;                   // whole waves only; there is no barrier in this kernel
-    const int t0 = HM == 6 ? a.t_begin : 0;                                    // first frame of this launch
-    const int Tl = song_length_of(a.lengths, song, T);
-    const int Tb = HM == 6 && a.t_end < Tl ? a.t_end : Tl;                     // one past the last frame of this launch
-    if (Tb <= t0) return;                                                      // (segments: the song ended before this one)
-    const ET* __restrict__ E = reinterpret_cast<const ET*>(a.logE) + (size_t)song * T * S;
-    float* __restrict__ hist = a.hist + (size_t)song * a.hist_rows * SDW;     // hist_rows = T (HM 0), (T + 1) / 2 (HM 1), segments (HM 5), K + 1 (HM 6)
-
+    const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wid >= (PK ? a.n_slots : a.B)) return; // whole waves only; there is no barrier in this kernel
     // ---------------- per-lane constants
     const int o = SDW - S;                                 // idle leading slots (>= 1)
     const int j0 = NPL * lane - o;                         // state of slot 0 of this lane (negative: idle)
@@ -213,8 +207,21 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
             for (int k = 0; k < NPL; ++k) xs[x][k] = j0 + k == a.extras[x];
         }
     }
-    // emission columns of this lane in rows >= 1 (see above); a single-row tensor (T == 1) never uses them
-    const long ecol = T > 1 ? (long)j0 : (long)(j0 < 0 ? 0 : j0);
+    const int k_begin = PK ? a.slot_begin[wid] : 0, k_end = PK ? a.slot_begin[wid + 1] : 1;
+    for (int kk = k_begin; kk < k_end; ++kk) {
+    // ---------------- this song: emission rows, history rows, length
+    const int song = PK ? a.slot_songs[kk] : wid;
+    const long long off = PK ? a.offsets[song] : (long long)song * a.T;           // first emission row of the song in the tensor
+    const int T = PK ? (int)(a.offsets[song + 1] - off) : a.T;                     // rows the song owns (packed: its length)
+    const int t0 = HM == 6 ? a.t_begin : 0;                                    // first frame of this launch
+    const int Tl = PK ? T : song_length_of(a.lengths, song, T);
+    const int Tb = HM == 6 && a.t_end < Tl ? a.t_end : Tl;                     // one past the last frame of this launch
+    if (Tb <= t0) continue;                                                    // (segments: the song ended before this one)
+    const ET* __restrict__ E = reinterpret_cast<const ET*>(a.logE) + (size_t)off * S;
+    float* __restrict__ hist = a.hist + (PK ? (size_t)off : (size_t)song * a.hist_rows) * SDW;     // hist_rows = T (HM 0), (T + 1) / 2 (HM 1), segments (HM 5), K + 1 (HM 6)
+    // emission columns of this lane in rows >= 1 (see above): the leading lanes reach back into the row in front -- of the same song,
+    // or (packed, row 0 is never loaded this way) of the song before it in the tensor; the first row of the tensor has none
+    const long ecol = (T > 1 || off > 0) ? (long)j0 : (long)(j0 < 0 ? 0 : j0);
     const int row_min = T > 1 ? 1 : 0;
     auto load_row = [&](int row, float (&e)[NPL]) {
         row = row < row_min ? row_min : row;
@@ -402,6 +409,7 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
             if (a.loglik) a.loglik[song] = bv;
         }
     }
+    }   // songs of this slot
 }
 
 template <int NPL, int D, int NX, typename ET>
@@ -428,6 +436,15 @@ static hipError_t launch_wave_x(const FwdArgs& a, hipStream_t st) {
         return hipGetLastError();
     }
 #endif
+    if (a.offsets) {            // packed batch (vit_decode_packed): one wave per slot, full history, rows at the songs' offsets
+        const int pgrid = (a.n_slots + 3) / 4;
+        if (a.n_slots <= 1024 && ((a.wave_flags & 2) || NX == 2)) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF1, 1, 7, ET>), dim3(pgrid), dim3(256), 0, st, a);
+        else if (NX == 1 && NPL == 6 && a.wave_u5 == 2) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 7, ET, (NX == 1 && NPL == 6) ? 2 : 0>), dim3(pgrid), dim3(256), 0, st, a);
+        else if (NX == 1 && NPL == 6 && a.wave_u5 == 3) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 7, ET, (NX == 1 && NPL == 6) ? 3 : 0>), dim3(pgrid), dim3(256), 0, st, a);
+        else if (NX == 1 && a.wave_u5 >= 1) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 7, ET, NX == 1 ? 1 : 0>), dim3(pgrid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 7, ET>), dim3(pgrid), dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
     if (a.ckpt_every > 0) {
         if (one) hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF1, 1, 5, ET>), dim3(grid), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((wave_forward_kernel<NPL, D, NX, PF2, 2, 5, ET>), dim3(grid), dim3(256), 0, st, a);

@@ -96,9 +96,20 @@ class ViterbiDecoder:
         workgroups and slow them down (B = 128: 10.04 instead of 10.22 ms per step, scripts/overlap_ab.py).  0 = the library's own
         count (what a single stream should use: the back-trace alone is fastest with every unit)."""
         n_cus = torch.cuda.get_device_properties(self.device).multi_processor_count
-        if B <= 0 or B >= n_cus:
-            return 0
-        return max(1, min(32, 16 * (n_cus - B) // B))      # (32: the library's cap, kBtMaxChunks)
+        if B <= 0 or 2 * (n_cus - B) < B:                  # fewer idle units than half the songs: the idle units alone would serialise the
+            return 0                                        # back-trace (B = 250 on 256 units: ONE chunk per song) -- the library's own count
+        return max(4, min(32, 16 * (n_cus - B) // B))      # (32: the library's cap, kBtMaxChunks)
+
+    FAMILIES = {1: "dense", 2: "group", 3: "wave"}
+
+    def forward_family(self, B: int, algo: str = "auto") -> str:
+        """The forward kernel family the library launches for this batch size (``vit_forward_family``): "dense" (any matrix, or
+        the step-structured kernel), "group" (banded, one song per workgroup) or "wave" (banded, one song per wavefront).  The
+        thresholds scale with the device's compute units -- ask, do not guess."""
+        fam = int(_lib.load().vit_forward_family(self._plan, int(B), _lib.ALGO[algo]))
+        if fam < 0:
+            _lib.check(fam, "vit_forward_family")
+        return self.FAMILIES[fam]
 
     # ------------------------------------------------------------------ workspace
     def workspace_bytes(self, B: int, T: int, algo: Optional[str] = None) -> int:
@@ -162,7 +173,13 @@ class ViterbiDecoder:
     def decode_into(self, logE: torch.Tensor, states: torch.Tensor, loglik: Optional[torch.Tensor] = None,
                     lengths: Optional[torch.Tensor] = None, algo: str = "auto", phase: str = "both", slot: int = 0) -> None:
         """Enqueue a decode on the current stream.  states: int32 [B,T]; loglik: float32 [B].
-        `phase` "forward" / "backtrace" run the two halves separately (same `slot` = same workspace)."""
+        `phase` "forward" / "backtrace" run the two halves separately (same `slot` = same workspace).
+
+        Lifetime rule of the split form: `logE` must be the SAME tensor, unchanged, in both phases -- with the wave form's half
+        history (``set_option("wave_history", 2)``) the back-trace reads 32 emission values of every odd frame again.  The
+        back-trace phase hands the pointer to the library (``vit_backtrace_checked``), which refuses a tensor other than the one
+        its forward pass decoded ("invalid argument"); a caller that double-buffers its emissions must keep a batch's buffer
+        untouched until that batch's back-trace has run."""
         lib = _lib.load()
         logE, _, dt = self._check_emissions(logE)
         B, T, _ = logE.shape
@@ -185,7 +202,7 @@ class ViterbiDecoder:
             elif phase == "forward":
                 rc = lib.vit_forward(self._plan, logE.data_ptr(), dt, B, T, len_ptr, ws_ptr, ws_bytes, ll_ptr, a, stream)
             elif phase == "backtrace":
-                rc = lib.vit_backtrace(self._plan, B, T, len_ptr, ws_ptr, ws_bytes, states.data_ptr(), a, stream)
+                rc = lib.vit_backtrace_checked(self._plan, logE.data_ptr(), dt, B, T, len_ptr, ws_ptr, ws_bytes, states.data_ptr(), a, stream)
             else:
                 raise ValueError(phase)
         _lib.check(rc, f"vit_{phase if phase != 'both' else 'decode'}")
@@ -253,6 +270,50 @@ class ViterbiDecoder:
         if out_dtype != torch.int32:
             states = states.to(out_dtype)
         return (states[0], loglik[0]) if single else (states, loglik)
+
+    # ------------------------------------------------------------------ packed (ragged) decode
+    def decode_packed(self, emission_logits: torch.Tensor, offsets, out_dtype: torch.dtype = torch.int64,
+                      workspace: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Decode B recordings of different lengths without padding (``vit_decode_packed``): ``emission_logits`` is
+        ``[sum T_b, S]`` (the rows of recording b are ``offsets[b] : offsets[b+1]``), ``offsets`` a host sequence of B + 1
+        frame offsets starting at 0.  Returns ``(states [sum T_b], loglik [B])``, packed like the input -- what the reference
+        computes recording by recording (tonet/for_paper.py:2304-2309).  Plans with the wave form only."""
+        lib = _lib.load()
+        if not isinstance(emission_logits, torch.Tensor) or emission_logits.device != self.device:
+            raise ValueError("emission_logits must be a torch tensor on the decoder's device")
+        if emission_logits.dim() != 2 or emission_logits.shape[1] != self.S or not emission_logits.is_contiguous():
+            raise ValueError(f"emission_logits must be a C-contiguous [sum T_b, {self.S}] tensor")
+        if emission_logits.dtype == torch.float32:
+            dt = _lib.VIT_F32
+        elif emission_logits.dtype == torch.float16:
+            dt = _lib.VIT_F16
+        else:
+            raise TypeError("emission_logits must be float32 or float16")
+        off = np.ascontiguousarray(offsets.cpu().numpy() if isinstance(offsets, torch.Tensor) else offsets, dtype=np.int64)
+        if off.ndim != 1 or off.size < 1 or off[0] != 0 or (np.diff(off) < 1).any() or off[-1] != emission_logits.shape[0]:
+            raise ValueError("offsets must be B + 1 strictly increasing frame offsets from 0 to the number of emission rows")
+        B, N = off.size - 1, int(off[-1])
+        states = torch.empty((N,), dtype=torch.int32, device=self.device)
+        loglik = torch.empty((B,), dtype=torch.float32, device=self.device)
+        if B > 0:
+            need = int(lib.vit_workspace_bytes_packed(self._plan, B, N))
+            if need == 0:
+                raise _lib.ViterbiHipError("the packed decode needs a plan with the wave form")
+            ws = workspace if workspace is not None else torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            if ws.dtype != torch.uint8 or ws.device != self.device or ws.numel() < need + 256:
+                raise ValueError(f"workspace must be a uint8 tensor of at least {need + 256} bytes on the decoder's device")
+            with torch.cuda.device(self.device):
+                rc = lib.vit_decode_packed(self._plan, emission_logits.data_ptr(), dt, B, off.ctypes.data, (ws.data_ptr() + 255) & ~255,
+                                           ws.numel() - 256, states.data_ptr(), loglik.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(rc, "vit_decode_packed")
+            if workspace is None:
+                torch.cuda.current_stream(self.device).synchronize()      # a workspace allocated here must outlive the kernels
+        if out_dtype != torch.int32:
+            states = states.to(out_dtype)
+        return states, loglik
+
+    def workspace_bytes_packed(self, B: int, total_frames: int) -> int:
+        return int(_lib.load().vit_workspace_bytes_packed(self._plan, int(B), int(total_frames)))
 
     def voicing(self, states: torch.Tensor, n_bins: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """voiced = state < n_bins, bins = min(state, n_bins-1) (tonet/for_paper.py:1828-1829)."""
