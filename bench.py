@@ -119,6 +119,14 @@ def make_params(transition, S, dmax):
     return synth.dense_random_log_transition(S, seed=3), synth.dense_random_log_transition(S, seed=4)[0].copy()
 
 
+def bound_of(kernel):
+    """roofline.bound: what binds the forward kernel ("hbm" only where it is HBM; `frac` is quoted against the HBM roofline whatever
+    this says, because that is the metric)."""
+    if kernel == "wave_forward_kernel":
+        return "hbm"          # full history: 5.2-5.5 TB/s of real traffic; (half history: vector issue -- the sweep rows say which)
+    return "latency" if kernel.startswith("banded") else "issue"
+
+
 def limited_by(kernel, B):
     """What actually binds the forward kernel (the roofline fraction is quoted against HBM whatever this says)."""
     if kernel == "wave_forward_kernel":
@@ -134,7 +142,7 @@ def forward_kernel_name(dec, algo, B, S):
     info = dec.info
     if algo in ("auto", "banded", "wave", "group") and info["banded_ok"]:
         nwt = next((w for w in (2, 4, 6, 8, 12) if w * 64 >= S), 0)
-        if algo == "wave" or (algo != "group" and info["wave_ok"] and B > 512):
+        if dec.forward_family(B, algo) == "wave":      # (vit_forward_family: the batch-size threshold scales with the device's compute units)
             return "wave_forward_kernel"
         floor_form = info["floor_ok"] and info["n_dense_rows"] == 0 and S < nwt * 64
         if not floor_form:
@@ -240,7 +248,11 @@ def cpu_baseline(logA_T, log_pi, E, gpu_states, gpu_loglik, seconds):
     out = {"value": frames / t_used / 1e6, "unit": "Mframes/s", "cores": 1, "kind": "port",
            "sample": f"first {done} of the batch's songs, T={T}, NumPy float32 loop (oracle/viterbi_oracle.py::decode_numpy)",
            "bit_exact_vs_gpu": exact, "numpy": np.__version__, "host": host_info()}
-    nthr = min(vo.num_threads(), 16)
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    nthr = max(1, min(vo.num_threads(), usable, E.shape[0]))      # every usable core, one song per thread (never more threads than songs)
     nb = min(E.shape[0], nthr)
     e = E[:nb].float().cpu().numpy()
     t0 = time.perf_counter()
@@ -249,7 +261,7 @@ def cpu_baseline(logA_T, log_pi, E, gpu_states, gpu_loglik, seconds):
     exact_c = bool(np.array_equal(st, gpu_states[:nb].cpu().numpy())) and bool(np.array_equal(ll, gpu_loglik[:nb].cpu().numpy()))
     out_c = {"value": nb * T / dt / 1e6, "unit": "Mframes/s", "cores": nthr, "kind": "port",
              "sample": f"{nb} songs, T={T}, scalar C restatement, one song per thread (oracle/viterbi_oracle.c)",
-             "bit_exact_vs_gpu": exact_c}
+             "usable_cores": usable, "bit_exact_vs_gpu": exact_c}
     return out, out_c
 
 
@@ -393,7 +405,193 @@ def sweep_row(dec, logA_T, log_pi, E, algo, steps, lengths=None, overlapped=True
     return r
 
 
-def extra_blocks(dev, args):
+def packed_row(dec, logA_T, log_pi, T, total_frames, dev, steps, seed=7):
+    """A ragged batch as the reference sees it (recordings decoded whole, each with its own T): lengths uniform in [T/4, T], as
+    many songs as hold `total_frames` frames, ONE packed [sum T_b, S] emission buffer, vit_decode_packed (forward slots packed
+    longest-first on the host, back-trace chunks of equal length).  Whole decode timed with HIP events on the current stream."""
+    S = dec.S
+    rng = np.random.default_rng(seed)
+    lens = []
+    left = total_frames
+    while left > 0:
+        n = int(rng.integers(T // 4, T + 1))
+        n = min(n, left)
+        lens.append(n)
+        left -= n
+    lens = np.asarray(lens, np.int64)
+    B = len(lens)
+    off = np.zeros(B + 1, np.int64)
+    off[1:] = np.cumsum(lens)
+    base = synth.emissions_peaks(32, T, S, seed=1234, device=dev)
+    E = torch.empty((int(off[-1]), S), dtype=torch.float32, device=dev)
+    for b in range(B):
+        E[off[b]:off[b + 1]] = base[b % 32, :lens[b]]
+    del base
+    need = dec.workspace_bytes_packed(B, int(off[-1]))
+    ws = torch.empty(need + 256, dtype=torch.uint8, device=dev)
+    st, ll = dec.decode_packed(E, off, out_dtype=torch.int32, workspace=ws)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(steps):
+        st, ll = dec.decode_packed(E, off, out_dtype=torch.int32, workspace=ws)
+    ev[1].record()
+    torch.cuda.synchronize()
+    ms = ev[0].elapsed_time(ev[1]) / steps
+    sub = [0, B // 2, B - 1, int(np.argmin(lens))]
+    from oracle import viterbi_oracle as vo
+    ok = True
+    for b in sub:
+        rs, rl = vo.decode_c(logA_T, log_pi, E[off[b]:off[b + 1]].unsqueeze(0).cpu().numpy())
+        ok = ok and bool(np.array_equal(st[off[b]:off[b + 1]].cpu().numpy(), rs[0])) and bool(ll[b].item() == rl[0])
+    n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    r = {"songs": B, "frames_decoded": int(off[-1]), "lengths": f"uniform in [{T // 4}, {T}], mean {float(lens.mean()):.0f}, shortest {int(lens.min())}",
+         "layout": "packed [sum T_b, S] emissions + host offsets (vit_decode_packed)", "forward_slots": int(min(B, 8 * n_cus)),
+         "ms_per_step": ms, "Mframes_per_s": int(off[-1]) / ms / 1e3,
+         "whole_path_hbm_frac": int(off[-1]) * (S * 4 + S * 2 + 6) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+         "workspace_GB": need / 1e9, "emissions_GB": E.numel() * 4 / 1e9, "bit_exact_vs_oracle_sample": ok}
+    del E, ws, st, ll
+    torch.cuda.empty_cache()
+    return r
+
+
+def checkpointed_row(dec, E, K, steps=3):
+    """vit_decode_checkpointed on batch E: wall clock of whole calls, workspace, and equality with the normal decode."""
+    B, T, _ = E.shape
+    need = dec.workspace_bytes_checkpointed(B, T, K)
+    ws = torch.empty(need + 256, dtype=torch.uint8, device=E.device)
+    want_s, want_l = dec.decode(E, algo="banded", out_dtype=torch.int32)
+    dec._ws = None
+    torch.cuda.empty_cache()
+    st, ll = dec.decode_checkpointed(E, segment_frames=K, out_dtype=torch.int32, workspace=ws)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st, ll = dec.decode_checkpointed(E, segment_frames=K, out_dtype=torch.int32, workspace=ws)
+    torch.cuda.synchronize()
+    ck_ms = (time.perf_counter() - t0) / steps * 1e3
+    r = {"songs": B, "segment_frames": K, "ms_per_step": ck_ms, "Mframes_per_s": B * T / ck_ms / 1e3,
+         "workspace_GB": need / 1e9, "workspace_GB_full_history": dec.workspace_bytes(B, T) / 1e9,
+         "equals_normal_decode": bool(torch.equal(st, want_s) and torch.equal(ll, want_l)),
+         "note": f"wall clock of {steps} whole calls (pass 1 + {(T + K - 1) // K} segments x (forward, back-trace)), wave form"}
+    del ws, st, ll, want_s, want_l
+    torch.cuda.empty_cache()
+    return r
+
+
+def pipeline_block(dev, T, steps):
+    """The post-processor callers actually run (Viterbi.__call__, tonet/for_paper.py:1817-1831): pitch logits [B, T, 360] ->
+    observation log-probabilities (vit_obs_shaun: peak picking + soft voicing, tonet/for_paper.py:1733-1778) -> Viterbi decode ->
+    voiced / bins (vit_voicing_map, :1828-1829), logits resident in HBM.  One stream: builder, forward, back-trace, map back to
+    back (HIP events around each); overlapped: the builder + back-trace + map of step i on a second stream beside the forward pass
+    of step i + 1 (two emission buffers, two workspace slots)."""
+    from viterbi_spl_amd import emissions
+    logA_T, log_pi = make_params("tonet", 361, 14)
+    dec = ViterbiDecoder(logA_T, log_pi, dev)
+    out = {}
+    for B in (128, 1024):
+        X = synth.pitch_logits(min(B, 32), T, 360, seed=5, device=dev)
+        if B > 32:
+            X = X.repeat(B // 32, 1, 1).contiguous()
+        E = [torch.empty((B, T, 361), dtype=torch.float32, device=dev) for _ in range(2)]
+        st = [torch.empty((B, T), dtype=torch.int32, device=dev) for _ in range(2)]
+        ll = [torch.empty((B,), dtype=torch.float32, device=dev) for _ in range(2)]
+        voiced = torch.empty((B, T), dtype=torch.uint8, device=dev)
+        bins = torch.empty((B, T), dtype=torch.int32, device=dev)
+        lib = __import__("viterbi_spl_amd._lib", fromlist=["x"]).load()
+
+        def vmap(k):
+            rc = lib.vit_voicing_map(st[k].data_ptr(), st[k].numel(), 360, voiced.data_ptr(), bins.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+            assert rc == 0
+
+        def one(k, ev=None):
+            if ev:
+                ev[0].record()
+            emissions.shaun_log_emissions(X, out=E[k])
+            if ev:
+                ev[1].record()
+            dec.decode_into(E[k], st[k], ll[k], algo="banded", phase="forward", slot=k)
+            if ev:
+                ev[2].record()
+            dec.decode_into(E[k], st[k], ll[k], algo="banded", phase="backtrace", slot=k)
+            if ev:
+                ev[3].record()
+            vmap(k)
+            if ev:
+                ev[4].record()
+
+        one(0)
+        torch.cuda.synchronize()
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(steps)]
+        for i in range(steps):
+            one(0, evs[i])
+        torch.cuda.synchronize()
+        ph = [float(np.mean([e[j].elapsed_time(e[j + 1]) for e in evs])) for j in range(4)]
+        total = float(np.mean([e[0].elapsed_time(e[4]) for e in evs]))
+        ref_states = st[0].clone()
+        # parity of the decode inside the pipeline: the oracle on the emission rows the builder produced (three songs)
+        from oracle import viterbi_oracle as vo
+        sub = [0, min(B, 32) // 2, min(B, 32) - 1]
+        rs, rl = vo.decode_c(logA_T, log_pi, E[0][sub].cpu().numpy())
+        exact = bool(np.array_equal(st[0][sub].cpu().numpy(), rs)) and bool(np.array_equal(ll[0][sub].cpu().numpy(), rl))
+        # overlapped: stream A = forward passes (critical path), stream B = builder of the next step, back-trace + map of the previous one
+        sA, sB = torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev)
+        dec.set_option("bt_chunks", dec.chunks_beside_forward(B))
+        built = [None, None]
+        fwd_done = [None, None]
+        bt_done = [None, None]
+
+        def run(n):
+            with torch.cuda.stream(sB):
+                emissions.shaun_log_emissions(X, out=E[0])
+                built[0] = torch.cuda.Event()
+                built[0].record()
+            for i in range(n):
+                k = i & 1
+                with torch.cuda.stream(sA):
+                    sA.wait_event(built[k])
+                    dec.decode_into(E[k], st[k], ll[k], algo="banded", phase="forward", slot=k)
+                    fwd_done[k] = torch.cuda.Event()
+                    fwd_done[k].record()
+                with torch.cuda.stream(sB):
+                    if i + 1 < n:                             # emissions of step i + 1 (its buffer is free once back-trace i - 1 has run: same stream)
+                        emissions.shaun_log_emissions(X, out=E[k ^ 1])
+                        built[k ^ 1] = torch.cuda.Event()
+                        built[k ^ 1].record()
+                    sB.wait_event(fwd_done[k])
+                    dec.decode_into(E[k], st[k], ll[k], algo="banded", phase="backtrace", slot=k)
+                    vmap(k)
+                    bt_done[k] = torch.cuda.Event()
+                    bt_done[k].record()
+            torch.cuda.synchronize()
+
+        run(2)
+        t0 = time.perf_counter()
+        run(steps)
+        ov = (time.perf_counter() - t0) / steps * 1e3
+        same = bool(torch.equal(st[(steps - 1) & 1], ref_states))
+        dec.set_option("bt_chunks", 0)
+        frames = B * T
+        bld_bytes = frames * (360 * 4 + 361 * 4)
+        out[f"B{B}"] = {"songs": B, "builder_ms": ph[0], "forward_ms": ph[1], "backtrace_ms": ph[2], "voicing_map_ms": ph[3], "one_stream_ms_per_step": total,
+                        "Mframes_per_s_one_stream": frames / total / 1e3, "overlapped_ms_per_step": ov, "Mframes_per_s_overlapped": frames / ov / 1e3,
+                        "Mframes_per_s_best": frames / min(total, ov) / 1e3, "overlapped_equals_one_stream": same,
+                        "decode_bit_exact_vs_oracle_on_built_emissions": exact,
+                        "builder": {"kernel": "observation_kernel (vit_obs_shaun, spw 5)", "Mframes_per_s": frames / ph[0] / 1e3,
+                                    "roofline": {"bound": "hbm", "bytes_per_frame": 360 * 4 + 361 * 4, "achieved": bld_bytes / (ph[0] * 1e-3) / 1e9,
+                                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bld_bytes / (ph[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+                        "bytes_per_frame_logits_to_path": 360 * 4 + 361 * 4 + 361 * 4 + 361 * 2 + 6 + 5,
+                        "voiced_fraction": float((voiced != 0).float().mean().item())}
+        del X, E, st, ll, voiced, bins, ref_states
+        dec._ws = None
+        dec._ws_slots = {}
+        torch.cuda.empty_cache()
+    out["workload"] = (f"pitch logits [B, {T}, 360] fp32 resident in HBM (noise floor + melody-like bumps, songs repeat with period 32) -> vit_obs_shaun -> "
+                       f"decode (tonet transition) -> vit_voicing_map; {steps} timed steps")
+    return out
+
+
+def extra_blocks(dev, args, headline_fwd_ms=None):
     """The saturation sweep and the high-resolution configuration, measured in this process after the headline."""
     out = {}
     T = args.frames
@@ -421,29 +619,37 @@ def extra_blocks(dev, args):
         lengths = torch.randint(T // 4, T + 1, (B,), generator=g, dtype=torch.int64).to(dev)
         sweep[f"B{B}_ragged"] = sweep_row(dec, logA_T, log_pi, E, "banded", NS, lengths=lengths, overlapped=False)
         sweep[f"B{B}_ragged"]["lengths"] = f"uniform in [{T // 4}, {T}], mean {float(lengths.float().mean()):.0f}; block order (not sorted)"
-        sweep[f"B{B}_ragged"]["forward_ms_if_all_full_length"] = sweep[f"B{B}"]["forward_ms"] if f"B{B}" in sweep else None
+        sweep[f"B{B}_ragged"]["forward_ms_if_all_full_length"] = sweep[f"B{B}"]["forward_ms"] if f"B{B}" in sweep else headline_fwd_ms if B == args.batch else None
         del E
         torch.cuda.empty_cache()
-    # bounded-workspace decode (vit_decode_checkpointed): checkpoint rows in pass 1, segments of 1024 frames re-run and back-traced
-    B, K = 256, 1024
-    E = tiled_emissions(synth.emissions_peaks, B, T, 361, 1234, dev, torch.float32)
-    need = dec.workspace_bytes_checkpointed(B, T, K)
-    ws = torch.empty(need + 256, dtype=torch.uint8, device=dev)
-    want_s, want_l = dec.decode(E, algo="banded", out_dtype=torch.int32)
-    st, ll = dec.decode_checkpointed(E, segment_frames=K, out_dtype=torch.int32, workspace=ws)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        st, ll = dec.decode_checkpointed(E, segment_frames=K, out_dtype=torch.int32, workspace=ws)
-    torch.cuda.synchronize()
-    ck_ms = (time.perf_counter() - t0) / 3 * 1e3
-    sweep["B256_checkpointed"] = {"songs": B, "segment_frames": K, "ms_per_step": ck_ms, "Mframes_per_s": B * T / ck_ms / 1e3,
-                                  "workspace_GB": need / 1e9, "workspace_GB_full_history": dec.workspace_bytes(B, T) / 1e9,
-                                  "equals_normal_decode": bool(torch.equal(st, want_s) and torch.equal(ll, want_l)),
-                                  "note": "wall clock of 3 whole calls (pass 1 + 30 segments x (forward, prep, back-trace)), wave form"}
-    del E, ws, st, ll, want_s, want_l
-    dec._ws = None
-    torch.cuda.empty_cache()
+    # the reference's shipped parameters (msnet/viterbi_transition_matrix.dat, S = 321: the three-group wave variant)
+    try:
+        gp = np.load(os.path.join(ROOT, "tests", "golden", "params.npz"))
+        mA, mpi = gp["msnet321_logA_T"], gp["msnet321_log_pi"]
+        mdec = ViterbiDecoder(mA, mpi, dev)
+        E = tiled_emissions(synth.emissions_peaks, 2048, T, 321, 1234, dev, torch.float32)
+        sweep["B2048_msnet321"] = sweep_row(mdec, mA, mpi, E, "banded", NS, overlapped=False)
+        sweep["B2048_msnet321"]["parameters"] = "msnet/viterbi_transition_matrix.dat + viterbi_init_probs.dat (payload in tests/golden/params.npz), S = 321"
+        del E, mdec
+        torch.cuda.empty_cache()
+    except Exception as ex:            # (the fixture is part of the repo; a failure here must not cost the whole line)
+        sweep["B2048_msnet321"] = {"error": repr(ex)}
+    # a ragged batch as the reference sees it: packed layout + slot packing, as many frames as the uniform B = 2048 row
+    try:
+        sweep["B3277_ragged_packed"] = packed_row(dec, logA_T, log_pi, T, 2048 * T, dev, NS)
+        if "B2048" in sweep:
+            sweep["B3277_ragged_packed"]["vs_uniform_B2048_one_stream"] = sweep["B3277_ragged_packed"]["Mframes_per_s"] / sweep["B2048"]["Mframes_per_s"]
+    except Exception as ex:
+        sweep["B3277_ragged_packed"] = {"error": repr(ex)}
+    # bounded-workspace decode (vit_decode_checkpointed): checkpoint rows in pass 1, segments of K frames re-run and back-traced
+    for B, K in ((256, 1024), (1024, 1024), (2048, 1024)):
+        E = tiled_emissions(synth.emissions_peaks, B, T, 361, 1234, dev, torch.float32)
+        sweep[f"B{B}_checkpointed"] = checkpointed_row(dec, E, K)
+        if f"B{B}" in sweep:
+            sweep[f"B{B}_checkpointed"]["vs_normal_decode"] = sweep[f"B{B}_checkpointed"]["Mframes_per_s"] / sweep[f"B{B}"]["Mframes_per_s"]
+        del E
+        dec._ws = None
+        torch.cuda.empty_cache()
     out["sweep"] = {"workload": f"T={T}, S=361, fp32 log-emissions (peaks unless the row says dense), tonet transition; songs repeat with period 32; "
                                 f"{NS} timed steps per row: forward + back-trace back to back on one stream (forward_ms, backtrace_ms, Mframes_per_s) and "
                                 "the two-stream schedule of the headline (overlapped_*); *_hbm_frac on algorithmic bytes (SURVEY 8d); "
@@ -464,6 +670,10 @@ def extra_blocks(dev, args):
         c4[name] = r
         del E, dec
         torch.cuda.empty_cache()
+    try:
+        out["pipeline"] = pipeline_block(dev, T, NS)
+    except Exception as ex:
+        out["pipeline"] = {"error": repr(ex)}
     out["configs4"] = {"workload": f"[256, {T}, 722] fp16 log-emissions (peaks), songs repeat with period 32 (BASELINE configs[4]); "
                                    f"{NS} timed steps: one stream (forward_ms, backtrace_ms, Mframes_per_s) and the headline's two-stream schedule (overlapped_*)", **c4}
     return out
@@ -619,7 +829,7 @@ def main():
                          ("; non-blocking gather on the communicator's stream" if use_dist else "")),
             "distributed": None if not use_dist else {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": ranks_info,
                                                       "gathers_launched_on_rank0": pipe.launched, "gather": "non-blocking dist.gather of states [B,T] int32 + loglik [B] to rank 0 per step"},
-            "roofline": {"bound": "hbm", "limited_by": limited_by(fwd_kernel, B), "kernel": fwd_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": bound_of(fwd_kernel), "limited_by": limited_by(fwd_kernel, B), "kernel": fwd_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": fwd_bytes, "avg_launch_ms": fwd_ms, "bytes_per_frame": bpf,
                          "note": "algorithmic bytes per SURVEY 8d (emission row in + uint16 back-pointer row out); the kernels "
@@ -660,7 +870,7 @@ def main():
                 dec._ws = None
                 dec._ws_slots = {}
                 torch.cuda.empty_cache()
-                out.update(extra_blocks(dev, args))
+                out.update(extra_blocks(dev, args, fwd_ms))
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
     if dist.is_initialized():

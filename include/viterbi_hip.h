@@ -207,7 +207,7 @@ int vit_decode_checkpointed(const vit_plan *plan, const void *logE, int emis_dty
  * Plans with the wave form only (vit_plan_info reserved[2] bit 3; VIT_EUNSUPPORTED otherwise): the forward pass runs
  * min(B, 8 x compute units) wavefronts, each decoding a host-packed list of songs back to back (longest-first greedy bins by
  * frame count), so a launch costs (total frames / wavefronts), not its longest song, and neither memory nor time is spent on
- * padding; the back-trace cuts every song into chunks of about equal length.  The library builds the slot and chunk tables on
+ * padding; the back-trace cuts every song into chunks of about equal length, one chunk per lane ("backtrace_form" 4's kernels).  The library builds the slot and chunk tables on
  * the host from `offsets` and uploads them through a pinned staging buffer it owns (it waits for the previous call's upload
  * before reusing it; otherwise no host synchronisation).  Bit-identical to vit_decode() of each song alone.
  */

@@ -154,3 +154,52 @@ def test_forward_family_query(golden, dev):
     assert dense.forward_family(64, "auto") == "dense"
     with pytest.raises(_lib.ViterbiHipError):
         dense.forward_family(64, "wave")
+
+
+def test_workspace_budget_policy(golden, dev):
+    """ViterbiDecoder.decode(max_workspace_bytes=...): full history -> half history -> checkpointed decode as the budget shrinks,
+    the same states and log-likelihoods in every mode, a loud error when nothing fits."""
+    A, pi = golden["params"]["tonet361_logA_T"], golden["params"]["tonet361_log_pi"]
+    dec = ViterbiDecoder(A, pi, dev)
+    B, T = 9, 4100
+    E = synth.emissions_peaks(B, T, 361, seed=3, device=dev)
+    lens = torch.tensor([T, 1, 2, 1500, T - 1, 3, 2049, 65, 4096], dtype=torch.int64, device=dev)
+    ref_s, ref_l = vo.decode_c(A, pi, E.cpu().numpy(), lengths=lens.cpu().numpy())
+    full = dec.workspace_bytes(B, T, "auto")
+    seen = []
+    for budget in (None, full, full - 1, full // 2 + 4096, full // 3, full // 8, full // 20):
+        mode = dec.plan_workspace(B, T, "auto", budget)
+        seen.append(mode["mode"])
+        assert budget is None or mode["workspace_bytes"] <= budget
+        st, ll = dec.decode(E, lengths=lens, out_dtype=torch.int32, max_workspace_bytes=budget)
+        assert np.array_equal(st.cpu().numpy(), ref_s) and np.array_equal(ll.cpu().numpy(), ref_l), (budget, mode)
+    assert seen[:2] == ["full", "full"] and "half" in seen and seen[-1] == "checkpointed", seen
+    assert dec._options.get("wave_history", 0) == 0                           # the policy leaves the plan's options as it found them
+    with pytest.raises(_lib.ViterbiHipError, match="fits a workspace"):
+        dec.decode(E, max_workspace_bytes=100000)
+    dense = ViterbiDecoder(golden["params"]["dense97_logA_T"], golden["params"]["dense97_log_pi"], dev)
+    with pytest.raises(_lib.ViterbiHipError, match="fits a workspace"):      # no wave form: nothing to fall back to
+        dense.decode(synth.emissions_dense(4, 300, 97, seed=1, device=dev), max_workspace_bytes=1000)
+
+
+def test_family_b_and_c_at_full_length(dev):
+    """The S = 361 production entry points themselves at T = 30000: Viterbi.viterbi_librosa_fn on F-order
+    [S, T] probabilities and SoftMaxViterbi.viterbi_librosa_fn on C-order [T, S] probabilities, against the states the reference's
+    own methods (tonet/for_paper.py:1833-1870, :1999-2037; AST-extracted by tests/golden/make_familyB_golden.py) returned."""
+    import hashlib
+    import json
+    import os
+    from tests.golden import make_familyB_golden as mk
+    from viterbi_spl_amd import reference_api as ra
+    gdir = os.path.dirname(mk.__file__)
+    man = json.load(open(os.path.join(gdir, "familyB_manifest.json")))
+    gold = np.load(os.path.join(gdir, "familyB_goldens.npz"))
+    A, pi = synth.tonet_transition(360, 14), synth.floored_prior(361)
+    assert mk.sha(A, pi) == man["sha256_params"]
+    P = mk.inputs(man["seed"], man["T"])
+    assert P.flags["F_CONTIGUOUS"] and hashlib.sha256(np.ascontiguousarray(P).tobytes()).hexdigest() == man["sha256_probs_st"]
+    want = gold["states_B"].astype(np.int64)
+    got = ra.Viterbi(A, pi, device=dev).viterbi_librosa_fn(P.copy(order="F"))
+    assert got.dtype == np.int64 and got.shape == (man["T"],) and np.array_equal(got, want)
+    got = ra.SoftMaxViterbi(A, pi, device=dev).viterbi_librosa_fn(np.array(P.T, order="C"))
+    assert np.array_equal(got, gold["states_C"].astype(np.int64))

@@ -273,16 +273,30 @@ __global__ void __launch_bounds__(kLnThreads) lane_spec_kernel(BtArgs a) {
     ln_load_tables<WQ, GT>(a, tabL, loL);
     (void)WX1;
     const int lane = threadIdx.x & 63;
-    const int C = a.chunks, S = a.S, SD = a.SD;
+    const int S = a.S, SD = a.SD;
+    const bool packed = a.offsets != nullptr;
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    int song = (int)(g / C);
-    const int chunk = (int)(g % C);
-    bool valid = song < a.B;
-    song = valid ? song : (int)a.B - 1;
-    if (a.skip_nonpositive && a.lengths[song] < 1) valid = false;       // segment of a checkpointed decode this song does not reach
-    const int Tb = ln_song_length(a, song), Lf = Tb - 1;
-    int32_t* __restrict__ states = a.states + (size_t)song * a.states_stride;
-    const float* __restrict__ hist = a.hist + (size_t)song * a.hist_rows * SD;
+    int song, chunk, C;
+    bool valid;
+    if (packed) {                           // (song, chunk) from the host-built stream table; a song's chunk count grows with its length
+        valid = g < a.n_waves;
+        song = a.wave_song[valid ? g : 0];
+        const int cb = a.chunk_base[song];
+        C = a.chunk_base[song + 1] - cb;
+        chunk = valid ? (int)g - cb : 0;
+    } else {
+        C = a.chunks;
+        song = (int)(g / C);
+        chunk = (int)(g % C);
+        valid = song < a.B;
+        song = valid ? song : (int)a.B - 1;
+        if (a.skip_nonpositive && a.lengths[song] < 1) valid = false;       // segment of a checkpointed decode this song does not reach
+    }
+    const long long off = packed ? a.offsets[song] : 0;
+    const int Tb = packed ? (int)(a.offsets[song + 1] - off) : ln_song_length(a, song), Lf = Tb - 1;
+    int32_t* __restrict__ states = a.states + (packed ? (size_t)off : (size_t)song * a.states_stride);
+    const float* __restrict__ hist = a.hist + (packed ? (size_t)off : (size_t)song * a.hist_rows) * SD;
+    int32_t* __restrict__ entry = a.entry + (packed ? (size_t)a.chunk_base[song] : (size_t)song * C);
     int lo_c, hi_c;
     ln_chunk_bounds(Lf, chunk, C, lo_c, hi_c);
     if (valid && chunk == C - 1) states[Tb - 1] = a.last_state[song];
@@ -330,7 +344,7 @@ __global__ void __launch_bounds__(kLnThreads) lane_spec_kernel(BtArgs a) {
         }
     }
     out.flush(states, t + 1);
-    if (valid) a.entry[(size_t)song * C + chunk] = entry_v;
+    if (valid) entry[chunk] = entry_v;
     if (valid && a.counters && decide.n_full) atomicAdd(a.counters + (size_t)song * kBtCounters + kCtFullRows, decide.n_full);
 }
 
@@ -344,17 +358,30 @@ __global__ void lane_pad_kernel(BtArgs a) {      // eight workgroups per song
 
 // Verify: thread per (song, chunk c < C-1): did chunk c assume at its upper boundary what chunk c+1 decided there?
 __global__ void lane_verify_kernel(BtArgs a, uint32_t* __restrict__ mask) {
-    const int C = a.chunks;
+    const bool packed = a.offsets != nullptr;
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int song = (int)(g / C), c = (int)(g % C);
-    if (song >= a.B || c >= C - 1) return;
-    if (a.skip_nonpositive && a.lengths[song] < 1) return;
-    const int Lf = ln_song_length(a, song) - 1;
+    int song, c, C;
+    if (packed) {
+        if (g >= a.n_waves) return;
+        song = a.wave_song[g];
+        C = a.chunk_base[song + 1] - a.chunk_base[song];
+        c = (int)g - a.chunk_base[song];
+    } else {
+        C = a.chunks;
+        song = (int)(g / C);
+        c = (int)(g % C);
+        if (song >= a.B) return;
+        if (a.skip_nonpositive && a.lengths[song] < 1) return;
+    }
+    if (c >= C - 1) return;
+    const long long off = packed ? a.offsets[song] : 0;
+    const int Lf = (packed ? (int)(a.offsets[song + 1] - off) : ln_song_length(a, song)) - 1;
     int lo_c, hi_c;
     ln_chunk_bounds(Lf, c, C, lo_c, hi_c);
     if (hi_c <= lo_c) return;
-    const int truth = a.states[(size_t)song * a.states_stride + hi_c];
-    if (a.entry[(size_t)song * C + c] != truth) atomicOr(mask + (size_t)song * kLaneMaskWords + (c >> 5), 1u << (c & 31));
+    const int truth = a.states[(packed ? (size_t)off : (size_t)song * a.states_stride) + hi_c];
+    const int32_t* entry = a.entry + (packed ? (size_t)a.chunk_base[song] : (size_t)song * C);
+    if (entry[c] != truth) atomicOr(mask + (size_t)song * kLaneMaskWords + (c >> 5), 1u << (c & 31));
 }
 
 // Repair: one lane per song walks the chunks whose guess was wrong, from the last to the first, re-chasing from the true
@@ -367,19 +394,23 @@ __global__ void __launch_bounds__(kLnThreads) lane_repair_kernel(BtArgs a, const
     int32_t* loL = reinterpret_cast<int32_t*>(smem);
     float* tabL = reinterpret_cast<float*>(loL + a.SP);
     const int lane = threadIdx.x & 63;
-    const int C = a.chunks, SD = a.SD;
+    const int SD = a.SD;
+    const bool packed = a.offsets != nullptr;
     int song = blockIdx.x * blockDim.x + threadIdx.x;
     bool valid = song < a.B;
     song = valid ? song : (int)a.B - 1;
+    const int C = packed ? a.chunk_base[song + 1] - a.chunk_base[song] : a.chunks;
     uint32_t mk[kLaneMaskWords];
     bool any_bit = false;
 #pragma unroll
     for (int w = 0; w < kLaneMaskWords; ++w) { mk[w] = valid ? mask[(size_t)song * kLaneMaskWords + w] : 0u; any_bit |= mk[w] != 0u; }
     if (!__syncthreads_or(any_bit)) return;          // nothing to repair in this workgroup (the common case)
     ln_load_tables<WQ, GT>(a, tabL, loL);
-    const int Lf = ln_song_length(a, song) - 1;
-    int32_t* __restrict__ states = a.states + (size_t)song * a.states_stride;
-    const float* __restrict__ hist = a.hist + (size_t)song * a.hist_rows * SD;
+    const long long off = packed ? a.offsets[song] : 0;
+    const int Lf = (packed ? (int)(a.offsets[song + 1] - off) : ln_song_length(a, song)) - 1;
+    int32_t* __restrict__ states = a.states + (packed ? (size_t)off : (size_t)song * a.states_stride);
+    const float* __restrict__ hist = a.hist + (packed ? (size_t)off : (size_t)song * a.hist_rows) * SD;
+    const int32_t* entry = a.entry + (packed ? (size_t)a.chunk_base[song] : (size_t)song * C);
     LaneDecider<WQ, GT, NWT> decide{a, tabL, loL, lane};
     decide.init();
     auto take_bit = [&](int& c_out) -> bool {        // highest chunk still flagged; clears it
@@ -439,7 +470,7 @@ __global__ void __launch_bounds__(kLnThreads) lane_repair_kernel(BtArgs a, const
                     repairing = false;               // frame 0 decided
                 } else {
                     clear_bit(c2);
-                    if (a.entry[(size_t)song * C + c2] == nxt) {
+                    if (entry[c2] == nxt) {
                         repairing = false;           // chunk c2 started from exactly this state
                     } else {
                         cc = c2;
@@ -474,9 +505,9 @@ bool lane_backtrace_applies(const BtArgs& a) {
 template <int WQ, bool GT, int NWT>
 static hipError_t launch_lane_t(const BtArgs& a, hipStream_t st, int phases) {
     const size_t lds = lane_lds_bytes(a, !GT);
-    const long long streams = (long long)a.B * a.chunks;
+    const long long streams = a.offsets ? (long long)a.n_waves : (long long)a.B * a.chunks;     // (packed: a.chunks = the largest per-song count)
     if (phases & 1) {
-        if (a.lengths && !a.skip_nonpositive) {
+        if (a.lengths && !a.skip_nonpositive && !a.offsets) {
             hipLaunchKernelGGL(lane_pad_kernel, dim3((unsigned)(8 * a.B)), dim3(256), 0, st, a);     // (segments of a checkpointed decode: filled by the caller)
         }
         hipLaunchKernelGGL((lane_spec_kernel<WQ, GT, NWT>), dim3((unsigned)((streams + kLnThreads - 1) / kLnThreads)), dim3(kLnThreads), lds, st, a);

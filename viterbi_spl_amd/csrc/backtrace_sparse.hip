@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
     constexpr int kSpNS = sp_span(KC);
     constexpr int kSpRS = kSpNS + kSpAux;             // floats per tile row
     constexpr int kSpVec = kSpK * kSpNS / 4 / 64;     // float4 per lane per tile
-    const int S = a.S, SP = a.SP, SD = a.SD, W = a.W;
+    const int S = a.S, SP = a.SP, SD = a.SD, T = a.T, W = a.W;
     const int nx = a.n_extras;
     const int WX1 = W + kMaxExtras + 1;    // candidate-table row: window, extras, row constant
     const int CB = W + kMaxExtras;         // candidate index of the bound (<= 63: checked by the launcher)
@@ -95,28 +95,15 @@ __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
     }
     __syncthreads();
 
-    const bool packed = a.offsets != nullptr;
+    const int C = a.chunks;
     const int gw = blockIdx.x * nwaves + wv;
-    int song, chunk, C;
-    if (packed) {                           // (song, chunk) from the host-built wave table; every song has its own chunk count
-        if (gw >= (MODE == 0 ? a.n_waves : (int)a.B)) return;
-        song = MODE == 0 ? a.wave_song[gw] : gw;
-        const int cb = a.chunk_base[song];
-        C = a.chunk_base[song + 1] - cb;
-        chunk = MODE == 0 ? gw - cb : 0;
-    } else {
-        C = a.chunks;
-        song = MODE == 0 ? gw / C : gw;
-        chunk = MODE == 0 ? gw % C : 0;
-    }
+    const int song = MODE == 0 ? gw / C : gw;
+    const int chunk = MODE == 0 ? gw % C : 0;
     if (song >= a.B) return;
     if (a.skip_nonpositive && a.lengths[song] < 1) return;        // segment of a checkpointed decode this song does not reach
-    const long long off = packed ? a.offsets[song] : 0;
-    const int T = packed ? (int)(a.offsets[song + 1] - off) : a.T;
-    const int Tb = packed ? T : sp_song_length(a.lengths, song, T);
-    int32_t* __restrict__ states = a.states + (packed ? (size_t)off : (size_t)song * a.states_stride);
-    const float* __restrict__ hist = a.hist + (packed ? (size_t)off : (size_t)song * a.hist_rows) * SD;
-    int32_t* __restrict__ entry = a.entry + (packed ? (size_t)a.chunk_base[song] : (size_t)song * C);     // [C] states the chunks assumed
+    const int Tb = sp_song_length(a.lengths, song, T);
+    int32_t* __restrict__ states = a.states + (size_t)song * a.states_stride;
+    const float* __restrict__ hist = a.hist + (size_t)song * a.hist_rows * SD;
     float* tile = tiles + wv * kSpK * kSpRS;
 
     // ---- per-lane constants, per candidate slot: candidates 0 .. W-1 the window, W .. W+nx-1 the extra columns, CB the bound
@@ -380,18 +367,18 @@ __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
             cur = idx == 0x7fffffffu ? 0 : (int)idx;
         }
         if (hi_c <= lo_c) {                       // empty chunk (very short song)
-            if (lane == 0) entry[chunk] = cur;
+            if (lane == 0) a.entry[(size_t)song * C + chunk] = cur;
             return;
         }
         cur = chase(top, hi_c, cur, false);       // warm-up: frames top .. hi_c, nothing written
-        if (lane == 0) entry[chunk] = cur;   // state this chunk assumed at frame hi_c
+        if (lane == 0) a.entry[(size_t)song * C + chunk] = cur;   // state this chunk assumed at frame hi_c
         chase(hi_c - 1, lo_c, cur, true);
     } else {
         int truth = -1;                           // verified state at frame hi_c of the chunk being checked
         for (int c = C - 2; c >= 0; --c) {
             const int lo_c = (int)((long long)Lf * c / C), hi_c = (int)((long long)Lf * (c + 1) / C);
             if (truth < 0) truth = __builtin_amdgcn_readfirstlane(states[hi_c]);
-            const int assumed = __builtin_amdgcn_readfirstlane(entry[c]);
+            const int assumed = __builtin_amdgcn_readfirstlane(a.entry[(size_t)song * C + c]);
             if (hi_c > lo_c && assumed != truth) {
                 ++n_rep;
                 truth = chase(hi_c - 1, lo_c, truth, true);   // re-chase from the true state; ends at frame lo_c
@@ -432,7 +419,7 @@ static hipError_t launch_sparse_t(const BtArgs& a, hipStream_t st, int phases) {
     int nw = 16;
     while (nw > 4 && sparse_lds_bytes(a, nw, !GT) + 1024 > 160 * 1024) nw >>= 1;
     const size_t lds = sparse_lds_bytes(a, nw, !GT);
-    const long long waves0 = a.offsets ? (long long)a.n_waves : (long long)a.B * a.chunks;     // (packed: a.chunks = the largest per-song count)
+    const long long waves0 = (long long)a.B * a.chunks;
     hipError_t e = hipSuccess;
     if (phases & 1) {
         hipLaunchKernelGGL((sparse_backtrace_kernel<NWT, AFF, 0, KC, GT>), dim3((int)((waves0 + nw - 1) / nw)), dim3(nw * 64), lds, st, a);

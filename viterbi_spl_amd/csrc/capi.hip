@@ -721,8 +721,10 @@ int vit_decode_checkpointed(const vit_plan* plan, const void* logE, int emis_dty
 // [B, T_max, S] tensor wastes memory on the padding and a launch with one wavefront per song costs its LONGEST song.  Here the
 // emissions of B songs are one [sum T_b, S] buffer, the history and the states are packed the same way, and the forward pass
 // runs n_slots <= 8 waves per CU, each walking a host-packed list of songs back to back (longest-first greedy bins by frames:
-// the rule of sharded.shard_by_length), so that every wave carries about the same number of frames.  The back-trace cuts every
-// song into chunks of about equal length (total frames / resident waves), one wave per chunk.
+// the rule of sharded.shard_by_length), so that every wave carries about the same number of frames.  The back-trace is the lane
+// form (backtrace_lane.hip): every song is cut into chunks of about equal length (total frames / resident LANES), one lane per
+// chunk -- the one-stream-per-wavefront kernels hold 16 streams per CU, fewer than a ragged batch of thousands of songs needs
+// (3250 songs: a second round of waves, 14 instead of 6 ms).
 namespace {
 
 struct PkLayout {
@@ -731,7 +733,7 @@ struct PkLayout {
     size_t tables_bytes;      // offsets .. chunk_base: one contiguous upload
 };
 inline int64_t pk_slots(const vit_plan* p, int64_t B) { const int64_t cap = 8 * (int64_t)p->n_cus; return B < cap ? B : cap; }
-inline int64_t pk_max_waves(const vit_plan* p, int64_t B) { return B + 16 * (int64_t)p->n_cus; }
+inline int64_t pk_max_waves(const vit_plan* p, int64_t B) { return B + 16 * 64 * (int64_t)p->n_cus; }     // (song, chunk) streams of the back-trace: one per lane
 PkLayout pk_layout(const vit_plan* p, int64_t B, int64_t N) {
     PkLayout k;
     const size_t sd = (size_t)vit::wave_hist_stride(p->bp.wave_npl) * sizeof(float);
@@ -775,8 +777,16 @@ int vit_decode_packed(const vit_plan* plan, const void* logE, int emis_dtype, in
     const int64_t N = offsets[B];
     if (B == 0) return VIT_OK;
     if (!logE || !states) return VIT_EINVAL;
-    const PkLayout k = pk_layout(plan, B, N);
+    PkLayout k = pk_layout(plan, B, N);
     if (workspace_bytes < k.bytes) return VIT_EWORKSPACE;
+    {   // fewer slots than songs when the batch is short of frames: a slot's load should not fall below the longest song, which bounds
+        // the launch anyway (1623 songs of 7500..30000 frames: 1024 slots of ~30000 frames, one wave per SIMD, instead of 1623 waves
+        // of which the longest share their SIMDs to the end)
+        int64_t tmax = 1;
+        for (int64_t b = 0; b < B; ++b) tmax = std::max<int64_t>(tmax, offsets[b + 1] - offsets[b]);
+        const int64_t by_frames = std::max<int64_t>(1, N / tmax);
+        k.n_slots = std::min<int64_t>(k.n_slots, by_frames);
+    }
     stamp_erase(plan, workspace);
     hipStream_t st = (hipStream_t)stream;
     uint8_t* ws = static_cast<uint8_t*>(workspace);
@@ -827,15 +837,18 @@ int vit_decode_packed(const vit_plan* plan, const void* logE, int emis_dtype, in
         for (int64_t sl = 0; sl < k.n_slots; ++sl) h_slot_begin[sl + 1] = h_slot_begin[sl] + count[(size_t)sl];
         std::vector<int32_t> fill(h_slot_begin, h_slot_begin + k.n_slots);
         for (int32_t sng : order) h_slot_songs[fill[(size_t)slot_of[(size_t)sng]]++] = sng;     // a slot walks its songs longest first
-        // back-trace chunks: about (total frames / resident waves) frames each, never shorter than eight warm-ups
-        const int64_t resident = 16 * (int64_t)plan->n_cus;
-        int64_t cf = (N + resident - 1) / resident;
-        cf = cf < 8 * vit::kBtWarmSparse ? 8 * vit::kBtWarmSparse : cf;
+        // back-trace streams (one per lane: backtrace_lane.hip): chunks of about (total frames / resident lanes) frames, never shorter
+        // than four warm-ups, at most kLaneMaxChunks per song
+        const int64_t resident = 16 * 64 * (int64_t)plan->n_cus;
+        int64_t cf = (N + resident - 1) / resident, tmax = 0;
+        for (int64_t b = 0; b < B; ++b) tmax = std::max<int64_t>(tmax, offsets[b + 1] - offsets[b]);
+        cf = std::max<int64_t>(cf, 4 * vit::kBtWarmSparse);
+        cf = std::max<int64_t>(cf, (tmax + vit::kLaneMaxChunks - 1) / vit::kLaneMaxChunks);
         int64_t w = 0;
         for (int64_t b = 0; b < B; ++b) {
             const int64_t tb = offsets[b + 1] - offsets[b];
             int64_t c = (tb + cf / 2) / cf;
-            c = c < 1 ? 1 : (c > vit::kBtMaxChunks ? vit::kBtMaxChunks : c);
+            c = c < 1 ? 1 : (c > vit::kLaneMaxChunks ? vit::kLaneMaxChunks : c);
             h_chunk_base[b] = (int32_t)w;
             for (int64_t q = 0; q < c; ++q) h_wave_song[w + q] = (int32_t)b;
             w += c;
@@ -900,9 +913,9 @@ int vit_decode_packed(const vit_plan* plan, const void* logE, int emis_dtype, in
     b.n_waves = n_waves;
     b.chunks = (int)max_chunks;
     b.warm = plan->tune.bt_warm >= 0 ? plan->tune.bt_warm : vit::kBtWarmSparse;
-    b.bt_form = 0;
-    if (!vit::sparse_backtrace_applies(b)) return VIT_EUNSUPPORTED;
-    e = vit::launch_backtrace_sparse(b, st);
+    b.bt_form = 4;
+    if (!vit::lane_backtrace_applies(b)) return VIT_EUNSUPPORTED;
+    e = vit::launch_backtrace_lane(b, st);
     return e == hipSuccess ? VIT_OK : hip_fail(e);
 }
 

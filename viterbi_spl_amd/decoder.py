@@ -75,6 +75,7 @@ class ViterbiDecoder:
             stream.synchronize()  # host image is pageable: make the copy visible before anything else
         self._ws: Optional[torch.Tensor] = None
         self._ws_slots: dict = {}
+        self._options: dict = {}
 
     def __del__(self):
         try:
@@ -88,6 +89,10 @@ class ViterbiDecoder:
         """Kernel-selection override (``vit_plan_set_option``; keys in include/viterbi_hip.h).  Every setting decodes the
         same bits; ``set_option("reset", 0)`` restores the defaults."""
         _lib.check(_lib.load().vit_plan_set_option(self._plan, key.encode(), int(value)), f"vit_plan_set_option({key})")
+        if key == "reset":
+            self._options = {}
+        else:
+            self._options[key] = int(value)
 
     def chunks_beside_forward(self, B: int) -> int:
         """``bt_chunks`` for the two-stream schedule (the back-trace of batch i beside the forward pass of batch i + 1): while one
@@ -223,11 +228,60 @@ class ViterbiDecoder:
         ct = ws[start:start + B * n.value * 4].view(torch.int32).view(B, n.value).sum(dim=0).cpu().tolist()
         return {k: int(ct[i]) for i, k in enumerate(self.COUNTERS)}
 
+    def plan_workspace(self, B: int, T: int, algo: str = "auto", max_workspace_bytes: Optional[int] = None) -> dict:
+        """How a [B, T, S] batch is decoded under a workspace budget (bytes; None = whatever `algo` asks for):
+
+        * ``{"mode": "full"}``  -- the normal decode fits (one delta row per frame, or what the options already select);
+        * ``{"mode": "half"}``  -- the wave form with the rows of even frames only (``wave_history`` 2: half the workspace, a
+          slower back-trace), where the plan has it;
+        * ``{"mode": "checkpointed", "segment_frames": K}`` -- ``vit_decode_checkpointed`` with the largest K that fits (about
+          twice the forward work; wave-form plans).
+
+        Raises ViterbiHipError when nothing fits.  Every mode decodes the same bits."""
+        need = self.workspace_bytes(B, T, algo)
+        if max_workspace_bytes is None or need <= max_workspace_bytes:
+            return {"mode": "full", "workspace_bytes": need}
+        if self.info["wave_ok"] and algo in ("auto", "banded", "wave") and T >= 2:
+            lib = _lib.load()
+            prev = self._options.get("wave_history", 0)
+            _lib.check(lib.vit_plan_set_option(self._plan, b"wave_history", 2), "vit_plan_set_option(wave_history)")
+            half = int(lib.vit_workspace_bytes_for(self._plan, B, T, _lib.ALGO["wave"]))
+            _lib.check(lib.vit_plan_set_option(self._plan, b"wave_history", prev), "vit_plan_set_option(wave_history)")
+            if 0 < half <= max_workspace_bytes:
+                return {"mode": "half", "workspace_bytes": half}
+            K = 8192
+            while K >= 64:
+                ck = int(lib.vit_workspace_bytes_checkpointed(self._plan, B, T, K))
+                if 0 < ck <= max_workspace_bytes:       # the largest segment that fits: fewest launches
+                    return {"mode": "checkpointed", "segment_frames": K, "workspace_bytes": ck}
+                K //= 2
+        raise _lib.ViterbiHipError(f"no decode of a [{B}, {T}, {self.S}] batch fits a workspace of {max_workspace_bytes} bytes "
+                                   f"(the normal decode needs {need})")
+
     def decode(self, emission_logits: torch.Tensor, lengths: Optional[torch.Tensor] = None, algo: str = "auto",
-               out_dtype: torch.dtype = torch.int64) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Returns (states [B,T] or [T] of ``out_dtype`` (reference: int64), loglik float32 [B] or scalar)."""
+               out_dtype: torch.dtype = torch.int64, max_workspace_bytes: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Returns (states [B,T] or [T] of ``out_dtype`` (reference: int64), loglik float32 [B] or scalar).
+
+        ``max_workspace_bytes``: a budget for the delta history (the reference keeps its work buffers for ONE song,
+        tonet/for_paper.py:1852-1853; a batch of 2048 full-length songs asks for 94 GB).  The decode falls from the full history to
+        the wave form's half history to the checkpointed decode (``plan_workspace``) instead of running out of memory; the result
+        is the same in every mode."""
         logE, single, _ = self._check_emissions(emission_logits)
         B, T, _ = logE.shape
+        if B > 0 and max_workspace_bytes is not None:
+            mode = self.plan_workspace(B, T, algo, int(max_workspace_bytes))
+            if mode["mode"] == "checkpointed":
+                st, ll = self.decode_checkpointed(logE, segment_frames=mode["segment_frames"], lengths=lengths, out_dtype=out_dtype)
+                return (st[0], ll[0]) if single else (st, ll)
+            if mode["mode"] == "half":
+                prev = self._options.get("wave_history", 0)
+                self.set_option("wave_history", 2)
+                self._ws = None                              # (a larger buffer kept from an earlier decode would defeat the budget)
+                try:
+                    st, ll = self.decode(logE, lengths=lengths, algo="wave", out_dtype=out_dtype)
+                finally:
+                    self.set_option("wave_history", prev)
+                return (st[0], ll[0]) if single else (st, ll)
         states = torch.empty((B, T), dtype=torch.int32, device=self.device)
         loglik = torch.empty((B,), dtype=torch.float32, device=self.device)
         if B > 0:

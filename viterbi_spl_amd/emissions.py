@@ -27,13 +27,22 @@ def _check(logits: torch.Tensor, last: int) -> torch.Tensor:
     return logits
 
 
+def _out(out, shape, device) -> torch.Tensor:
+    if out is None:
+        return torch.empty(shape, dtype=torch.float32, device=device)
+    if out.dtype != torch.float32 or tuple(out.shape) != tuple(shape) or out.device != device or not out.is_contiguous():
+        raise ValueError(f"out must be a contiguous float32 {tuple(shape)} tensor on the logits' device")
+    return out
+
+
 def shaun_log_emissions(logits: torch.Tensor, voicing_threshold: float = 0.32, single_side_peak_width: int = 5,
-                        p: float = 0.8, scale: float = 2.0) -> torch.Tensor:
-    """``Viterbi.observation_probs_fn`` + log: logits ``[..., T, n_bins]`` -> log-emissions ``[..., T, n_bins+1]``."""
+                        p: float = 0.8, scale: float = 2.0, out: torch.Tensor | None = None) -> torch.Tensor:
+    """``Viterbi.observation_probs_fn`` + log: logits ``[..., T, n_bins]`` -> log-emissions ``[..., T, n_bins+1]`` (into ``out``
+    when given: a caller's emission buffer)."""
     n_bins = logits.shape[-1]
     logits = _check(logits, n_bins)
     assert 0 < voicing_threshold < 1
-    out = torch.empty(logits.shape[:-1] + (n_bins + 1,), dtype=torch.float32, device=logits.device)
+    out = _out(out, logits.shape[:-1] + (n_bins + 1,), logits.device)
     n = logits.numel() // n_bins
     with torch.cuda.device(logits.device):
         rc = _lib.load().vit_obs_shaun(logits.data_ptr(), n, n_bins, single_side_peak_width,
@@ -44,12 +53,12 @@ def shaun_log_emissions(logits: torch.Tensor, voicing_threshold: float = 0.32, s
     return out
 
 
-def softmax_log_emissions(logits: torch.Tensor, single_side_peak_width: int = 15) -> torch.Tensor:
+def softmax_log_emissions(logits: torch.Tensor, single_side_peak_width: int = 15, out: torch.Tensor | None = None) -> torch.Tensor:
     """``SoftMaxViterbi.observation_probs_fn`` + log: logits ``[..., T, n_bins+1]`` (column 0 = unvoiced) ->
     log-emissions ``[..., T, n_bins+1]`` with the unvoiced state last."""
     S = logits.shape[-1]
     logits = _check(logits, S)
-    out = torch.empty_like(logits)
+    out = _out(out, logits.shape, logits.device)
     n = logits.numel() // S
     with torch.cuda.device(logits.device):
         rc = _lib.load().vit_obs_softmax(logits.data_ptr(), n, S - 1, single_side_peak_width, out.data_ptr(),

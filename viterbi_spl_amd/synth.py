@@ -209,3 +209,20 @@ def dense_random_log_transition(S: int, seed: int = 0) -> np.ndarray:
     rows = torch.arange(S, dtype=torch.int64)
     h = _cell_hash(_mix32(rows ^ _song_base(seed ^ 0x68E31DA4, 0)), rows)
     return ((h % 5121).to(torch.float32) * (-1.0 / 256.0)).numpy()
+
+
+def pitch_logits(B: int, T: int, n_bins: int, seed: int = 0, device="cpu") -> torch.Tensor:
+    """Synthetic pitch logits ``[B, T, n_bins]`` float32 for the emission builders (bench.py's pipeline block): a weak noise floor
+    (mean -8, sd 1.5: an unvoiced frame) and, in two frames out of three, a melody-like five-bin bump whose centre drifts by a
+    bin or two per frame -- the shape of tests/common.logits_case, generated on the device."""
+    g = torch.Generator(device=device)
+    g.manual_seed(1000003 * seed + 17)
+    x = torch.randn((B, T, n_bins), generator=g, device=device) * 1.5 - 8.0
+    steps = torch.randint(-2, 3, (B, T), generator=g, device=device)
+    centre = (n_bins // 2 + torch.cumsum(steps, dim=1)) % (n_bins - 16) + 8
+    amp = torch.rand((B, T), generator=g, device=device) * 2.0 + 0.5
+    voiced = (torch.arange(T, device=device) % 3 != 0).to(x.dtype)[None, :] * amp
+    shape = torch.tensor([1.0, 3.0, 6.0, 3.0, 1.0], device=device)
+    for k in range(5):
+        x.scatter_add_(2, (centre + (k - 2)).unsqueeze(-1), (voiced * shape[k]).unsqueeze(-1))
+    return x
