@@ -201,6 +201,265 @@ __global__ void __launch_bounds__(kObsWaves * 64) observation_kernel(const float
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// observation_reg_kernel: the same builders with the frame in REGISTERS (round 4).  The LDS form above spends 393 vector +
+// 213 scalar + 100 LDS instructions per frame (profiles/r02_pmc_extras.txt) -- more vector work than the 233-instruction
+// forward recursion it feeds -- on staging the row, a doubling table and ballot / popcount ranks for the peak compaction.  Here
+// lane l owns NPL CONTIGUOUS bins (one coalesced vector load and store per lane), the SPW neighbours on either side arrive by
+// wave-wide DPP shifts of whole registers (wave_shr:1 / wave_shl:1, chained for SPW > NPL; -inf beyond the row's ends), every
+// window maximum is a chain of v_max3_f32 over registers with compile-time indices, and the reflect padding is never built: what
+// it adds to the windows reduces to two rules at the left end (at the kernel).  exp / log run densely on the owner lanes with the
+// hardware's v_exp_f32 / v_log_f32 and a compensated range scaling (a few ulp) instead of through a compacted peak list, the
+// wave reductions are DPP; the soft-voicing sigmoid stays in float64 like the reference's.  No LDS, no barrier.
+// Instantiated for the reference's half-widths 5 ("shaun", dcnet's scaled likelihood) and 15 (softmax) and 5 / 6 / 8 / 12 bins per
+// lane (U <= 64 NPL: the 320-, 360- and 721-bin grids and what lies between); other geometries keep the LDS form.
+namespace {
+
+typedef float ob_f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float ob_f2u __attribute__((ext_vector_type(2), aligned(4)));
+
+// a lane's NPL consecutive floats as 16- / 8- / 4-byte pieces at 4-byte alignment (coalesced across the wave)
+template <int NPL>
+__device__ __forceinline__ void ob_load(const float* __restrict__ p, float (&v)[NPL]) {
+    int k = 0;
+#pragma unroll
+    for (; k + 3 < NPL; k += 4) { const ob_f4u t = *reinterpret_cast<const ob_f4u*>(p + k); v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w; }
+#pragma unroll
+    for (; k + 1 < NPL; k += 2) { const ob_f2u t = *reinterpret_cast<const ob_f2u*>(p + k); v[k] = t.x; v[k + 1] = t.y; }
+    if (k < NPL) v[k] = p[k];
+}
+template <int NPL>
+__device__ __forceinline__ void ob_store(float* __restrict__ p, const float (&v)[NPL]) {
+    int k = 0;
+#pragma unroll
+    for (; k + 3 < NPL; k += 4) { ob_f4u t; t.x = v[k]; t.y = v[k + 1]; t.z = v[k + 2]; t.w = v[k + 3]; *reinterpret_cast<ob_f4u*>(p + k) = t; }
+#pragma unroll
+    for (; k + 1 < NPL; k += 2) { ob_f2u t; t.x = v[k]; t.y = v[k + 1]; *reinterpret_cast<ob_f2u*>(p + k) = t; }
+    if (k < NPL) p[k] = v[k];
+}
+
+__device__ __forceinline__ float ob_shr1(float x) {   // lane l <- x[l-1]; lane 0 (no source) gets -inf: the bins in front of the row
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-INFINITY), __float_as_int(x), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float ob_shl1(float x) {   // lane l <- x[l+1]; lane 63 gets -inf
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-INFINITY), __float_as_int(x), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float ob_wave_max(float x) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(x));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+__device__ __forceinline__ float ob_wave_sum(float x) {   // inclusive scan by rows, lane 63 holds the total
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(x));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+// e^x through v_exp_f32 (2^y, 1 ulp): log2(e) = hi + lo, the rounding error of x * hi is recovered with an fma and applied as
+// the factor 2^lo ~ 1 + lo ln 2 -- ~2 ulp where a plain x * log2(e) would lose |x| * 1e-7
+__device__ __forceinline__ float ob_exp(float x) {
+    const float hi = x * 1.44269502f;
+    const float lo = __builtin_fmaf(x, 1.44269502f, -hi);              // the product's rounding error, exactly
+    const float e2 = __builtin_amdgcn_exp2f(hi);
+    return __builtin_fmaf(e2, lo * 0.693147182f, e2);                   // (what float(log2 e) itself is off by adds |x| * 1.3e-8: < 1 ulp up to |x| = 8)
+}
+// ln y through v_log_f32 (log2, 1 ulp), ln 2 = hi + lo
+__device__ __forceinline__ float ob_log(float y) {
+    const float l2 = __builtin_amdgcn_logf(y);
+    return __builtin_fmaf(l2, 0.693147182f, l2 * -1.90465421e-9f);
+}
+
+}  // namespace
+
+template <int NPL, int SPW, int MODE>
+__global__ void __launch_bounds__(256) observation_reg_kernel(const float* __restrict__ logits, int64_t n_frames, int U, double threshold,
+                                                             double offset, double scale, const float* __restrict__ prior,
+                                                             float* __restrict__ out) {
+    constexpr int H = (SPW + NPL - 1) / NPL;          // lanes a lane looks at on either side
+    constexpr int NA = NPL + 2 * SPW;                 // local neighbourhood: bins NPL*lane - SPW .. NPL*lane + NPL + SPW - 1
+    const int lane = threadIdx.x & 63;
+    const int in_stride = MODE == 1 ? U + 1 : U;
+    const int in_off = MODE == 1 ? 1 : 0;
+    const int S = U + 1;
+    // ---- per-lane geometry: slot k of lane l is bin NPL*l + k.  The reflect padding of the reference (np.pad 'reflect': x[-k] = x[k],
+    //      x[U-1+k] = x[U-1-k]) never has to exist: beyond the row's ends the neighbourhood holds -inf, and what the mirrored values
+    //      add to a window is already in it -- except at the left end, where the LEFT window is compared strictly:
+    //        bin 0:              its left window is the mirror of its right one  ->  peak iff c > max(right window)
+    //        bins 1 .. SPW / 2:  their left window contains their own mirror image ->  never a peak (c > c)
+    //        every other bin:    the mirrored values are bins the window holds anyway (left end), or add c >= x for bins that the
+    //                            strict left comparison covers (right end; the last bin's right window is all mirror: c >= -inf)
+    bool real[NPL], never[NPL], first[NPL];
+    float rprior[NPL];                                // MODE 2: 1 / prior of the bin
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int b = NPL * lane + k;
+        real[k] = b < U;
+        never[k] = b >= 1 && 2 * b <= SPW;
+        first[k] = b == 0;
+        rprior[k] = (MODE == 2 && prior && real[k]) ? 1.f / prior[b] : 1.f;
+    }
+    const float rprior_u = (MODE == 2 && prior) ? 1.f / prior[U] : 1.f;
+    // a full lane's NPL columns are one contiguous, coalesced vector access; the one partial lane of a row whose length is not a
+    // multiple of NPL goes column by column; lanes beyond the row hold -inf and store nothing
+    const int col0 = NPL * lane;
+    const bool full = col0 + NPL <= U, partial = !full && col0 < U;
+    const int64_t fstep = (int64_t)gridDim.x * (blockDim.x >> 6);
+    int64_t f = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform: row bases in scalar registers
+    // two frames in flight per wave (two register sets, the loop unrolled by two): with eight waves per SIMD one row ahead left the
+    // kernel waiting on HBM latency at 4.2 TB/s
+    float xq[2][NPL];
+    float x0q[2] = {0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) xq[q][k] = -INFINITY;
+    auto fetch = [&](const int64_t fr, float (&xn)[NPL], float& x0n) {
+        const float* __restrict__ x = logits + fr * in_stride + in_off;
+        if (full) ob_load<NPL>(x + col0, xn);
+        if (partial) {
+#pragma unroll
+            for (int k = 0; k < NPL; ++k)
+                if (real[k]) xn[k] = x[col0 + k];
+        }
+        if (MODE == 1) x0n = logits[fr * in_stride];
+    };
+    if (f < n_frames) fetch(f, xq[0], x0q[0]);
+    if (f + fstep < n_frames) fetch(f + fstep, xq[1], x0q[1]);
+    auto process = [&](const int64_t f, float (&xn)[NPL], float& x0n) {
+        float* __restrict__ o = out + f * S;
+        float a[NA];
+        const float x0f = x0n;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) a[SPW + k] = xn[k];
+        if (f + 2 * fstep < n_frames) fetch(f + 2 * fstep, xn, x0n);
+        // ---- neighbours: a[SPW - d] = bin NPL*lane - d lives in lane - ceil(d / NPL); shifted copies chained; a lane without a source
+        //      keeps -inf (the DPP `old` operand)
+        {
+            float sl[NPL], sr[NPL];
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) { sl[k] = a[SPW + k]; sr[k] = a[SPW + k]; }
+#pragma unroll
+            for (int h = 1; h <= H; ++h) {
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) {
+                    const int dl = h * NPL - k;               // sl[k] after h shifts = bin NPL*(lane-h) + k = own start - dl
+                    if (dl <= SPW) { sl[k] = ob_shr1(sl[k]); a[SPW - dl] = sl[k]; }      // (a slot that is out of reach at h stays out of reach)
+                    const int dr = (h - 1) * NPL + k;         // sr[k] after h shifts = bin NPL*(lane+h) + k = own end + 1 + dr
+                    if (dr < SPW) { sr[k] = ob_shl1(sr[k]); a[SPW + NPL + dr] = sr[k]; }
+                }
+            }
+        }
+        // ---- peaks: the FIRST maximum of its window: c > max(left SPW) and c >= max(right SPW)
+        bool pk[NPL];
+        float lmax = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            float ml = a[k], mr = a[SPW + k + 1];
+#pragma unroll
+            for (int j = 1; j + 1 < SPW; j += 2) { ml = fmaxf(fmaxf(ml, a[k + j]), a[k + j + 1]); mr = fmaxf(fmaxf(mr, a[SPW + k + 1 + j]), a[SPW + k + 2 + j]); }
+            if (SPW % 2 == 0) { ml = fmaxf(ml, a[k + SPW - 1]); mr = fmaxf(mr, a[2 * SPW + k]); }
+            const float c = a[SPW + k];
+            const bool std_pk = c > ml && c >= mr, first_pk = c > mr;
+            pk[k] = real[k] && !never[k] && (first[k] ? first_pk : std_pk);
+            lmax = pk[k] ? fmaxf(lmax, c) : lmax;
+        }
+        const float x0 = MODE == 1 ? x0f : (MODE == 2 ? (float)threshold : -INFINITY);     // the unvoiced logit (always in the peak set)
+        float g = ob_wave_max(lmax);
+        const bool any_peak = g > -INFINITY;
+        if (MODE >= 1) g = fmaxf(g, x0);
+        float ex[NPL];
+        float lsum = 0.f;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            ex[k] = ob_exp(pk[k] ? a[SPW + k] - g : -1000.f);          // (e^-1000 = 0: a select on the argument, no branch around the exp)
+            lsum += ex[k];
+        }
+        float tot = ob_wave_sum(lsum);
+        float last;                                      // probability of the unvoiced state
+        float v[NPL];
+        if (MODE == 0) {
+            // soft voicing on the strongest peak (tonet/for_paper.py:1703-1712, :1757-1764) in float64 exactly like the reference:
+            // 1 - expit(s) is formed by subtraction there, so for s > ~37 the unvoiced probability is EXACTLY 0 (-> log tiny) and below
+            // that it carries the float64 cancellation noise of the reference (2e-5 relative at 1 - pv = 6e-12); a float32 expit(-s)
+            // would be more accurate and would not be the reference's number
+            double pv = 0.0;
+            if (any_peak) {
+                const double gd = (double)g;
+                const double s_ = gd >= threshold ? scale * (gd - threshold) + offset : scale * (gd - threshold) - offset;
+                if (s_ > 0) pv = 1.0 / (1.0 + exp(-s_));
+                else { const double q = exp(s_); pv = q / (1.0 + q); }
+            }
+            const double t = any_peak ? pv / (double)tot : 0.0;
+            last = any_peak ? (float)(1.0 - pv) : 1.f;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                float lg = ob_log((float)((double)ex[k] * t) + kTiny);
+                asm volatile("" : "+v"(lg));                          // (evaluate, then select: no branch per slot)
+                v[k] = pk[k] ? lg : kLogTiny;
+            }
+        } else {
+            const float e0 = ob_exp(x0 - g);
+            tot += e0;
+            const float tf = 1.f / tot;
+            last = any_peak ? e0 * tf : 1.f;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                float pr = ex[k] * tf;
+                if (MODE == 2) pr *= rprior[k];
+                float lg = ob_log(pr + kTiny);
+                asm volatile("" : "+v"(lg));                          // (evaluate, then select: no branch per slot)
+                v[k] = pk[k] ? lg : kLogTiny;
+            }
+        }
+        if (full) ob_store<NPL>(o + col0, v);
+        if (partial) {
+#pragma unroll
+            for (int k = 0; k < NPL; ++k)
+                if (real[k]) o[col0 + k] = v[k];
+        }
+        if (MODE == 2) last *= rprior_u;                 // (a peak-less frame: 1 / prior)
+        if (lane == 0) o[U] = ob_log(last + kTiny);
+    };
+    for (; f < n_frames; f += 2 * fstep) {
+        process(f, xq[0], x0q[0]);
+        if (f + fstep < n_frames) process(f + fstep, xq[1], x0q[1]);
+    }
+}
+
+template <int NPL, int SPW, int MODE>
+static hipError_t launch_obs_reg(const float* logits, int64_t n_frames, int U, double thr, double off, double sc, const float* prior,
+                                 float* out, int n_cus, hipStream_t st) {
+    int64_t blocks = (n_frames + 3) / 4;
+    if (blocks > (int64_t)n_cus * 8) blocks = (int64_t)n_cus * 8;      // eight waves per SIMD: the resident capacity, every wave walks its frames
+    hipLaunchKernelGGL((observation_reg_kernel<NPL, SPW, MODE>), dim3((int)blocks), dim3(256), 0, st, logits, n_frames, U, thr, off, sc, prior, out);
+    return hipGetLastError();
+}
+
 template <int MODE>
 static hipError_t launch_obs(const float* logits, int64_t n_frames, int U, int spw, double thr, double off, double sc,
                              const float* prior, float* out, hipStream_t st) {
@@ -211,6 +470,16 @@ static hipError_t launch_obs(const float* logits, int64_t n_frames, int U, int s
     if (n_cus == 0) {
         int dev = 0, cus = 0;
         n_cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? cus : 256;
+    }
+    // the register form for the reference's geometries (spw 5 / 15; 5, 6, 8 or 12 bins per lane)
+    if ((spw == 5 || spw == 15) && U > 64 && U > 2 * spw) {
+#define VIT_OBS_REG(N) return spw == 5 ? launch_obs_reg<N, 5, MODE>(logits, n_frames, U, thr, off, sc, prior, out, n_cus, st) \
+                                      : launch_obs_reg<N, 15, MODE>(logits, n_frames, U, thr, off, sc, prior, out, n_cus, st)
+        if (U <= 64 * 5) VIT_OBS_REG(5);
+        if (U <= 64 * 6) VIT_OBS_REG(6);
+        if (U <= 64 * 8) VIT_OBS_REG(8);
+        if (U <= 64 * 12) VIT_OBS_REG(12);
+#undef VIT_OBS_REG
     }
     if (blocks > (int64_t)n_cus * 6) blocks = (int64_t)n_cus * 6;   // six workgroups of four frames' LDS fit a CU: one resident wave per frame slot, no second round
     const size_t lds = sizeof(float) * kObsWaves * 4 * (U + 2 * spw + 1);
