@@ -177,6 +177,14 @@ def time_serial(dec, E, algo, steps, warmup=1, lengths=None):
     return {"wall_ms_per_step": wall / steps * 1e3, "forward_ms": fwd, "backtrace_ms": bt}, st, ll
 
 
+# configs[4] kernels, per frame and song (one song per workgroup), from the SQ counters of profiles/r04_pmc_configs4.txt
+# ([256, 30000, 722] fp16, ten launches): SQ_INSTS_VALU / frames, SQ_LDS_IDX_ACTIVE / frames
+C4_ISSUE_PROFILE = {
+    "jdc_band_dmax40": {"kernel": "banded_floor_forward_kernel<84,12,1,4,half>", "valu_instructions_per_frame_and_song": 1302,
+                        "lds_active_cycles_per_frame_and_song": 1329, "source": "profiles/r04_pmc_configs4.txt"},
+    "durrieu_dense": {"kernel": "step4s_forward_kernel<20,9,2,half>", "valu_instructions_per_frame_and_song": 1020,
+                      "lds_active_cycles_per_frame_and_song": 1268, "source": "profiles/r04_pmc_configs4.txt"},
+}
 VALU_LANE_RATE = 256 * 4 * 16 * 2.4e9   # lane-instructions per second: 256 CUs x 4 SIMDs x 16 lanes per clock at 2.4 GHz
 
 
@@ -655,26 +663,38 @@ def extra_blocks(dev, args, headline_fwd_ms=None):
                                 "the two-stream schedule of the headline (overlapped_*); *_hbm_frac on algorithmic bytes (SURVEY 8d); "
                                 "ragged rows count the frames actually decoded", **sweep}
     del dec
-    # ---- configs[4]: S=722 (721 bins + unvoiced), fp16 emissions, 256 songs
+    # ---- configs[4]: S=722 (721 bins + unvoiced), fp16 emissions, 256 songs (and 512: two songs per CU cover each other's barriers)
     c4 = {}
+    n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
     for name, tr, dmax in (("jdc_band_dmax40", "tonet", 40), ("durrieu_dense", "durrieu", None)):
         A, pi = make_params(tr, 722, dmax or 14)
         dec = ViterbiDecoder(A, pi, dev)
-        E = tiled_emissions(synth.emissions_peaks, 256, T, 722, 1234, dev, torch.float16)
-        r = sweep_row(dec, A, pi, E, "auto", NS, overlapped=True)
-        if dec.info["banded_ok"]:
-            r["valu_ceiling"] = valu_ceiling(dec, 722, 256 * T, r["forward_ms"])
-        else:   # the step-structured kernel shares its band maxima between targets: there is no per-candidate instruction floor to quote
-            r["valu_ceiling"] = None
-            r["valu_ceiling_note"] = "not defined for the step-structured kernel (band maxima are shared between the four targets of a lane; DESIGN.md 4.2b)"
-        c4[name] = r
-        del E, dec
+        for B4 in (256, 512):
+            E = tiled_emissions(synth.emissions_peaks, B4, T, 722, 1234, dev, torch.float16)
+            r = sweep_row(dec, A, pi, E, "auto", NS, overlapped=True)
+            if dec.info["banded_ok"]:
+                r["valu_ceiling"] = valu_ceiling(dec, 722, B4 * T, r["forward_ms"])
+            # issue ceiling of THIS kernel from its measured instruction mix (rocprofv3 --pmc SQ counters of the same kernel and shape,
+            # profiles/r04_pmc_configs4.txt): vector instructions per frame and song spread over a CU's four SIMDs at one wave64
+            # instruction per four cycles, and the LDS pipe's active cycles per frame; a CU works on one song's frame at a time
+            prof = C4_ISSUE_PROFILE[name]
+            cyc = max(prof["valu_instructions_per_frame_and_song"], prof["lds_active_cycles_per_frame_and_song"])
+            peak = n_cus * 2.4e9 / cyc
+            ic = {**prof, "cycles_per_frame_and_cu_at_the_ceiling": cyc, "peak_Mframes_per_s": peak / 1e6,
+                  "achieved_Mframes_per_s": B4 * T / (r["forward_ms"] * 1e-3) / 1e6, "frac": B4 * T / (r["forward_ms"] * 1e-3) / peak}
+            r["issue_ceiling"] = ic
+            if not dec.info["banded_ok"]:   # the step-structured kernel shares its band maxima between targets: no per-candidate floor, the issue ceiling stands in
+                r["valu_ceiling"] = ic
+            c4[name if B4 == 256 else f"{name}_B{B4}"] = r
+            del E
+            torch.cuda.empty_cache()
+        del dec
         torch.cuda.empty_cache()
     try:
         out["pipeline"] = pipeline_block(dev, T, NS)
     except Exception as ex:
         out["pipeline"] = {"error": repr(ex)}
-    out["configs4"] = {"workload": f"[256, {T}, 722] fp16 log-emissions (peaks), songs repeat with period 32 (BASELINE configs[4]); "
+    out["configs4"] = {"workload": f"[256, {T}, 722] fp16 log-emissions (peaks), songs repeat with period 32 (BASELINE configs[4]; the _B512 rows: 512 songs); "
                                    f"{NS} timed steps: one stream (forward_ms, backtrace_ms, Mframes_per_s) and the headline's two-stream schedule (overlapped_*)", **c4}
     return out
 

@@ -6,8 +6,9 @@ cd "$(dirname "$0")/.."
 ROOT=$(pwd)
 export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/prof_r04
-rm -rf $OUT && mkdir -p $OUT
+[ -z "$ONLY_PMC" ] && rm -rf $OUT; mkdir -p $OUT
 cd /tmp
+if [ -z "$ONLY_PMC" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/scripts/prof_r04.py > $OUT/stats.log 2> $OUT/stats.err
 # per (kernel, grid) rows from the trace: the same kernel at 1024 and 2048 songs must not share a line
 python3 - "$OUT/stats" > $OUT/r04_kernel_stats.csv <<'PY'
@@ -23,10 +24,11 @@ for (k, g, w), v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
 PY
 find $OUT -name "*kernel_trace.csv" -delete
 echo "kernel stats done"; cat $OUT/r04_kernel_stats.csv | cut -c1-200
+fi
 pmc() {   # pmc NAME PART...: SQ counters (two passes) + FETCH_SIZE / WRITE_SIZE (one pass each), no tracing domain
     name=$1; shift
     rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/$name/sq1 -- python3 $ROOT/scripts/prof_r04.py "$@" > /dev/null 2>> $OUT/err.log
-    rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --output-format csv -d $OUT/$name/sq2 -- python3 $ROOT/scripts/prof_r04.py "$@" > /dev/null 2>> $OUT/err.log
+    rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/$name/sq2 -- python3 $ROOT/scripts/prof_r04.py "$@" > /dev/null 2>> $OUT/err.log
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/$name/fetch -- python3 $ROOT/scripts/prof_r04.py "$@" > /dev/null 2>> $OUT/err.log
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/$name/write -- python3 $ROOT/scripts/prof_r04.py "$@" > /dev/null 2>> $OUT/err.log
     python3 - "$OUT/$name" "$*" > $OUT/r04_pmc_$name.txt <<'PY'
@@ -50,7 +52,12 @@ PY
     find $OUT/$name -name "*counter_collection.csv" -delete
     echo "pmc $name done"
 }
-pmc obs obs
-pmc lane lane
-pmc b1024 b1024
+if [ -n "$ONLY_PMC" ]; then
+    for part in $ONLY_PMC; do pmc $part $part; done     # e.g. ONLY_PMC="configs4" scripts/profile_r04.sh
+else
+    pmc obs obs
+    pmc lane lane
+    pmc b1024 b1024
+    pmc configs4 configs4
+fi
 ls -la $OUT
