@@ -1,6 +1,7 @@
 """Randomised parity run (test infrastructure; run on the GPU box): random state counts, band half-widths, matrix families,
 batch shapes, ragged lengths, emission kinds and storage types; every kernel family the plan allows and both back-trace forms, the wave
-form's half history and the checkpointed decode against the C restatement in oracle/.  argv: seconds to run (default 240), seed (default 1)."""
+form's half history, the checkpointed decode, the lane form of the back-trace (chunk counts up to 256) and the packed decode against the C
+restatement in oracle/.  argv: seconds to run (default 240), seed (default 1)."""
 import os
 import sys
 import time
@@ -72,23 +73,37 @@ while time.time() - t0 < budget:
         forms = [("auto", 0)]
         if dec.info["banded_ok"]:
             forms += [("group", 0), ("group", 2)]
+            if dec.info["n_dense_rows"] == 0:
+                forms += [("group", 4)]           # one (song, chunk) stream per lane
             if dec.info["wave_ok"]:
-                forms += [("wave", 0), ("wave", 2), ("wave-half", 0), ("checkpointed", 0)]
+                forms += [("wave", 0), ("wave", 2), ("wave", 4), ("wave-half", 0), ("checkpointed", 0), ("packed", 0)]
         if S <= 400 or rng.random() < 0.3:
             forms += [("dense", 0)]
         chunks = int(rng.choice([0, 0, 2, 7, 32]))
+        lane_chunks = int(rng.choice([0, 1, 3, 64, 100, 256]))
         warm = int(rng.choice([0, 1, 16, 64]))
         n_cases += 1
         for algo, btf in forms:
             dec.set_option("backtrace_form", btf)
             dec.set_option("bt_fast_rows", n_cases % 3 == 0)      # every third case: all rows through the sparse kernels' general code
-            if chunks:
+            if btf == 4:
+                dec.set_option("bt_chunks", lane_chunks)
+                dec.set_option("bt_warm", warm)
+            elif chunks:
                 dec.set_option("bt_chunks", chunks)
                 dec.set_option("bt_warm", warm)
             try:
                 if algo == "wave-half":          # even delta rows only; refused (loudly) where the plan does not allow it
                     dec.set_option("wave_history", 2)
                     st, ll = dec.decode(E, lengths=lens, algo="wave", out_dtype=torch.int32)
+                elif algo == "packed":           # the songs' valid frames in one buffer, no padding
+                    off = np.zeros(B + 1, np.int64)
+                    off[1:] = np.cumsum(lens_np)
+                    Ep = torch.cat([E[b, :int(lens_np[b])] for b in range(B)], dim=0).contiguous()
+                    sp, ll = dec.decode_packed(Ep, off, out_dtype=torch.int32)
+                    st = torch.full((B, T), -1, dtype=torch.int32, device=dev)
+                    for b in range(B):
+                        st[b, :int(lens_np[b])] = sp[off[b]:off[b + 1]]
                 elif algo == "checkpointed":
                     st, ll = dec.decode_checkpointed(E, segment_frames=int(rng.choice([64, 65, 100, 256, 2048])), lengths=lens, out_dtype=torch.int32)
                 else:
