@@ -99,3 +99,25 @@ def test_observation_oracle_matches_reference_goldens():
         seed, n = og[f"softmax{k}_seed"]
         got = oo.softmax_observation_probs(logits_case(int(seed), int(n), 361))
         assert np.array_equal(got, og[f"softmax{k}_probs"])
+
+
+def test_c_oracle_matches_family_b_goldens_at_full_length():
+    """The S = 361 production entry points' goldens (tests/golden/make_familyB_golden.py: the reference's own
+    Viterbi.viterbi_librosa_fn / SoftMaxViterbi.viterbi_librosa_fn at T = 30000): inputs regenerate bit for bit, and the C
+    restatement - fed log(p + tiny) computed as the reference does - returns the reference's states."""
+    import json
+    import os
+    from tests.golden import make_familyB_golden as mk
+    from viterbi_spl_amd import synth
+    gdir = os.path.dirname(mk.__file__)
+    man = json.load(open(os.path.join(gdir, "familyB_manifest.json")))
+    gold = np.load(os.path.join(gdir, "familyB_goldens.npz"))
+    A, pi = synth.tonet_transition(360, 14), synth.floored_prior(361)
+    assert mk.sha(A, pi) == man["sha256_params"]
+    P = mk.inputs(man["seed"], man["T"])
+    assert mk.sha(P) == man["sha256_probs_st"]
+    logA_T, log_pi = vo.log_params_from_probs(A, pi)
+    logE = np.require(np.log(P.T + vo.TINY32), np.float32, ["C"])
+    states, _ = vo.decode_c(logA_T, log_pi, logE)
+    assert np.array_equal(states, gold["states_B"].astype(np.int32)) and np.array_equal(gold["states_B"], gold["states_C"])
+    assert int(np.sum(states == 360)) == man["unvoiced_frames"]
