@@ -209,7 +209,9 @@ int vit_decode_checkpointed(const vit_plan *plan, const void *logE, int emis_dty
  * frame count), so a launch costs (total frames / wavefronts), not its longest song, and neither memory nor time is spent on
  * padding; the back-trace cuts every song into chunks of about equal length, one chunk per lane ("backtrace_form" 4's kernels).  The library builds the slot and chunk tables on
  * the host from `offsets` and uploads them through a pinned staging buffer it owns (it waits for the previous call's upload
- * before reusing it; otherwise no host synchronisation).  Bit-identical to vit_decode() of each song alone.
+ * before reusing it; otherwise no host synchronisation).  Bit-identical to vit_decode() of each song alone.  Not thread-safe against
+ * concurrent packed decodes on the same plan (one staging buffer per plan); `lengths`-style padding does not exist here, so states
+ * carries no -1 entries.
  */
 size_t vit_workspace_bytes_packed(const vit_plan *plan, int64_t B, int64_t total_frames);
 int vit_decode_packed(const vit_plan *plan, const void *logE, int emis_dtype, int64_t B, const int64_t *offsets,

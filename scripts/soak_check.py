@@ -25,12 +25,25 @@ def run(name, logA_T, log_pi, B, T, f16, kind="dense"):
     forms = [("auto", 0)] * 3
     if dec.info["banded_ok"]:
         forms += [("group", 0), ("group", 2)]
+        if dec.info["n_dense_rows"] == 0:
+            forms += [("group", 4), ("group", 4)]          # one (song, chunk) stream per lane
         if dec.info["wave_ok"]:
-            forms += [("wave", 0), ("wave", 2), ("wave", 0)]
+            forms += [("wave", 0), ("wave", 2), ("wave", 0), ("wave", 4), ("packed", 0), ("packed", 0)]
     forms += [("dense", 0)]
     for algo, btf in forms:
         dec.set_option("backtrace_form", btf)
-        st, ll = dec.decode(E, lengths=lens, algo=algo, out_dtype=torch.int32)
+        if algo == "packed":                               # the songs' valid frames in one buffer (vit_decode_packed); compared after unpacking
+            ln = lens.cpu().numpy()
+            off = np.zeros(B + 1, np.int64)
+            off[1:] = np.cumsum(ln)
+            Ep = torch.cat([E[b, :int(ln[b])] for b in range(B)], dim=0).contiguous()
+            sp, ll = dec.decode_packed(Ep, off, out_dtype=torch.int32)
+            st = torch.full((B, T), -1, dtype=torch.int32, device=dev)
+            idx = torch.arange(T, device=dev)[None, :] < lens[:, None]
+            st[idx] = sp
+            del Ep
+        else:
+            st, ll = dec.decode(E, lengths=lens, algo=algo, out_dtype=torch.int32)
         cur = (st.cpu().numpy().tobytes(), ll.cpu().numpy().tobytes())
         if ref is None:
             ref = cur
