@@ -203,3 +203,36 @@ def test_family_b_and_c_at_full_length(dev):
     assert got.dtype == np.int64 and got.shape == (man["T"],) and np.array_equal(got, want)
     got = ra.SoftMaxViterbi(A, pi, device=dev).viterbi_librosa_fn(np.array(P.T, order="C"))
     assert np.array_equal(got, gold["states_C"].astype(np.int64))
+
+
+def test_packed_decode_error_paths(golden, dev):
+    """vit_decode_packed at the C ABI: status codes, not exceptions -- bad offsets, a workspace that is too small, an empty batch."""
+    import ctypes
+    lib = _lib.load()
+    A, pi = golden["params"]["tonet361_logA_T"], golden["params"]["tonet361_log_pi"]
+    dec = ViterbiDecoder(A, pi, dev)
+    E = synth.emissions_peaks(1, 50, 361, seed=1, device=dev)[0].contiguous()
+    st = torch.empty((50,), dtype=torch.int32, device=dev)
+    ll = torch.empty((2,), dtype=torch.float32, device=dev)
+    need = dec.workspace_bytes_packed(2, 50)
+    assert need > 50 * 384 * 4
+    ws = torch.empty(need + 256, dtype=torch.uint8, device=dev)
+    wp = (ws.data_ptr() + 255) & ~255
+
+    def call(off, nbytes=need, B=None):
+        off = np.asarray(off, np.int64)
+        return lib.vit_decode_packed(dec._plan, E.data_ptr(), _lib.VIT_F32, len(off) - 1 if B is None else B, off.ctypes.data, wp, nbytes,
+                                     st.data_ptr(), ll.data_ptr(), None)
+    assert call([0, 20, 50]) == 0
+    torch.cuda.synchronize()
+    ref_s, ref_l = vo.decode_c(A, pi, np.stack([np.pad(E[:20].cpu().numpy(), ((0, 30), (0, 0))), np.pad(E[20:].cpu().numpy(), ((0, 20), (0, 0)))]),
+                               lengths=np.array([20, 30], np.int64))
+    assert np.array_equal(st[:20].cpu().numpy(), ref_s[0, :20]) and np.array_equal(st[20:].cpu().numpy(), ref_s[1, :30])
+    assert np.array_equal(ll.cpu().numpy(), ref_l)
+    assert call([1, 20, 50]) == -1                         # offsets must start at 0           (VIT_EINVAL)
+    assert call([0, 20, 20]) == -1                         # an empty song
+    assert call([0, 30, 20]) == -1                         # decreasing
+    assert call([0, 20, 50], nbytes=need - 1) == -4        # VIT_EWORKSPACE
+    assert call([0], B=0) == 0                             # nothing to do
+    assert lib.vit_decode_packed(dec._plan, E.data_ptr(), 7, 2, np.asarray([0, 20, 50], np.int64).ctypes.data, wp, need, st.data_ptr(), ll.data_ptr(), None) == -1
+    assert int(lib.vit_workspace_bytes_packed(None, 2, 50)) == 0
