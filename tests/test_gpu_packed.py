@@ -236,3 +236,21 @@ def test_packed_decode_error_paths(golden, dev):
     assert call([0], B=0) == 0                             # nothing to do
     assert lib.vit_decode_packed(dec._plan, E.data_ptr(), 7, 2, np.asarray([0, 20, 50], np.int64).ctypes.data, wp, need, st.data_ptr(), ll.data_ptr(), None) == -1
     assert int(lib.vit_workspace_bytes_packed(None, 2, 50)) == 0
+
+
+def test_postprocessor_over_many_recordings(golden, dev):
+    """reference_api.Viterbi / SoftMaxViterbi.decode_recordings: recordings of different lengths through one builder launch, one packed
+    decode and one voicing map -- every recording's (voiced, bins) equal to the post-processor run on that recording alone."""
+    from tests.common import logits_case
+    from viterbi_spl_amd import reference_api as ra
+    A, pi = synth.tonet_transition(360, 14), synth.floored_prior(361)
+    lens = [257, 1, 64, 1000, 2, 333, 129]
+    for cls, cols in ((ra.Viterbi, 360), (ra.SoftMaxViterbi, 361)):
+        vit = cls(A, pi, device=dev)
+        recs = [logits_case(100 + k, n, cols) for k, n in enumerate(lens)]
+        got = vit.decode_recordings(recs)
+        assert len(got) == len(lens)
+        for k, x in enumerate(recs):
+            v1, b1 = vit.decode_logits(x)
+            assert got[k][0].shape == (lens[k],) and torch.equal(got[k][0], v1) and torch.equal(got[k][1], b1), (cls.__name__, k)
+        assert vit.decode_recordings([]) == []

@@ -184,6 +184,23 @@ class _PreparedViterbi:
             return self._decoder.voicing(states, self.num_freq_bins)
         return self._decoder.voicing_notes(states, note_range, self.num_freq_bins)
 
+    def decode_recordings(self, logits_list):
+        """Many recordings in ONE pass: what the reference does recording by recording (one ``viterbi(logits)`` call each,
+        tonet/for_paper.py:2304-2319) as a single emission-builder launch over the concatenated frames, a single packed decode
+        (``vit_decode_packed``: no padding, forward slots packed by length) and a single voicing map.  ``logits_list``: NumPy or torch
+        ``[T_b, columns]`` per recording.  Returns a list of ``(voiced bool[T_b], bins int32[T_b])`` torch tensors on the GPU;
+        every pair equals ``decode_logits`` of that recording alone (the builders work frame by frame, the decode is bit-identical)."""
+        dev = self._decoder.device
+        parts = [(lg if isinstance(lg, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(lg, np.float32))).to(dev) for lg in logits_list]
+        if not parts:
+            return []
+        offsets = np.concatenate([[0], np.cumsum([int(x.shape[0]) for x in parts])]).astype(np.int64)
+        assert all(x.dim() == 2 and x.shape[1] == parts[0].shape[1] and x.shape[0] >= 1 for x in parts)
+        E = self._log_emissions(torch.cat(parts, dim=0).contiguous())
+        states, _ = self._decoder.decode_packed(E, offsets, out_dtype=torch.int32)
+        voiced, bins = self._decoder.voicing(states, self.num_freq_bins)
+        return [(voiced[offsets[b]:offsets[b + 1]], bins[offsets[b]:offsets[b + 1]]) for b in range(len(parts))]
+
     def __call__(self, logits):
         """``viterbi(logits) -> (voiced bool[T], bins int64[T])`` as NumPy arrays, the reference's call surface
         (tonet/for_paper.py:1817-1831, :2309).  The observation probabilities are built on the GPU (``vit_obs_*``: peak
