@@ -213,6 +213,10 @@ def time_overlapped(dec, E, algo, steps, warmup=1, lengths=None):
     s_fwd, s_bt = torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev)   # forward workgroups are dispatched first
     bt_done = [None, None]
     dec.set_option("bt_chunks", dec.chunks_beside_forward(B))      # the back-trace on the units the forward pass leaves idle
+    n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    small_groups = dec.history_mode(B, T, algo) == "half" and B <= 4 * n_cus
+    if small_groups:            # one forward wave per SIMD leaves 256 registers free: eight-wave back-trace workgroups (208) can start beside them,
+        dec.set_option("bt_block_waves", 8)     # sixteen-wave ones (416) cannot (B = 1024, half history: 22.1 -> 20.2 ms per step)
 
     def run(n):
         for i in range(n):
@@ -236,6 +240,8 @@ def time_overlapped(dec, E, algo, steps, warmup=1, lengths=None):
     wall = (time.perf_counter() - t0) / steps * 1e3
     dec._ws_slots.clear()
     dec.set_option("bt_chunks", 0)
+    if small_groups:
+        dec.set_option("bt_block_waves", 0)
     return wall, st[(steps - 1) & 1], ll[(steps - 1) & 1]
 
 

@@ -112,6 +112,9 @@ int vit_plan_query(const vit_plan *plan, vit_plan_info *info);
  *                      2 off (plain dense kernel) | 3 four targets per lane, one wave per lane group
  *   "bt_chunks", "bt_warm"   time-parallel back-trace: chunks per song (0 auto), warm-up frames (-1 default); "bt_fast_rows" 1 = every
  *                      row through the general code of the sparse kernels (0: the unexceptional rows run in a loop of their own)
+ *   "bt_block_waves"   half history's back-trace: waves per workgroup, 0 = 16 | 8 | 4.  Eight-wave workgroups (208 registers per SIMD) can start
+ *                      on a CU whose SIMDs each hold one 256-register forward wave, i.e. beside the next batch's forward pass at up to
+ *                      4 x CUs songs in flight (the two-stream schedule); sixteen-wave ones cannot
  *   "win_shift"        LDS window shift 0..3 (-1 from the plan); "wave_min_batch" (0 default), "wave_two" 1
  *   "wave_history"     wave form: 0 / 1 = store every delta row | 2 = store the rows of even frames only (the back-trace rebuilds
  *                      the 32 values an odd frame needs from the row before it and the emissions): half the workspace and a

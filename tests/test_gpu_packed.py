@@ -254,3 +254,23 @@ def test_postprocessor_over_many_recordings(golden, dev):
             v1, b1 = vit.decode_logits(x)
             assert got[k][0].shape == (lens[k],) and torch.equal(got[k][0], v1) and torch.equal(got[k][1], b1), (cls.__name__, k)
         assert vit.decode_recordings([]) == []
+
+
+def test_half_backtrace_with_small_workgroups(golden, dev):
+    """bt_block_waves: the half history's back-trace in workgroups of eight / four waves (the form that can start beside resident
+    forward waves) decodes the same bits as the sixteen-wave default, chunked and with forced bad guesses."""
+    A, pi = golden["params"]["tonet361_logA_T"], golden["params"]["tonet361_log_pi"]
+    dec = ViterbiDecoder(A, pi, dev)
+    E = synth.emissions_dense(19, 901, 361, seed=8, device=dev)
+    lens = torch.tensor([901, 1, 2, 900, 450, 3, 64, 65, 66, 4, 5, 901, 333, 17, 129, 800, 2, 640, 77], dtype=torch.int64, device=dev)
+    ref_s, ref_l = vo.decode_c(A, pi, E.cpu().numpy(), lengths=lens.cpu().numpy())
+    for waves in (0, 8, 4):
+        for chunks, warm in ((0, -1), (7, 0), (2, 5)):
+            dec.set_option("reset", 0)
+            dec.set_option("wave_history", 2)
+            dec.set_option("bt_block_waves", waves)
+            dec.set_option("bt_chunks", chunks)
+            dec.set_option("bt_warm", warm)
+            st, ll = dec.decode(E, lengths=lens, algo="wave", out_dtype=torch.int32)
+            assert np.array_equal(st.cpu().numpy(), ref_s) and np.array_equal(ll.cpu().numpy(), ref_l), (waves, chunks, warm)
+    dec.set_option("reset", 0)

@@ -486,7 +486,10 @@ bool half_backtrace_applies(const BtArgs& a) {
 
 template <typename ET>
 static hipError_t launch_half_t(const BtArgs& a, hipStream_t st, int phases) {
-    const int nw = 16;
+    // sixteen waves per workgroup by default; eight (or four) on request: with its 104 registers per lane a sixteen-wave workgroup needs
+    // 416 registers of every SIMD and cannot start on a CU whose SIMDs each hold a 256-register forward wave (1024 songs in flight); an
+    // eight-wave workgroup (208 per SIMD) can, which is what puts this back-trace UNDER the next batch's forward pass (BtArgs::block_waves)
+    const int nw = a.block_waves == 8 || a.block_waves == 4 ? a.block_waves : 16;
     const size_t lds = half_lds_bytes(a, nw);
     const long long waves0 = (long long)a.B * a.chunks;
     hipError_t e = hipSuccess;

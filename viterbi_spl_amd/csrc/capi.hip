@@ -36,6 +36,7 @@ struct Tuning {
     int wave_uniform = 0;      // wave form: 0 = the last-state / uniform-lane variants where the plan proves them (wave.hip UV) | 1 = neither |
                                // 2 = the last-state variant only | 3 = the three-group form where the two-group one would run (it is valid there too)
     int bt_fast_rows = 0;      // sparse / half back-trace: 0 = the unexceptional rows in their own loop | 1 = every row through the general code
+    int bt_block_waves = 0;    // half back-trace: waves per workgroup, 0 = 16 | 8 | 4 (to start beside the next batch's resident forward waves)
     int wave_history = 0;      // wave form: 0 / 1 every delta row | 2 the rows of even frames only (VIT_EUNSUPPORTED where the plan does not allow it)
     int timing = 0;
 };
@@ -281,7 +282,7 @@ static int* tuning_field(Tuning& t, const char* key) {
         {"dense_songs", &Tuning::dense_songs}, {"dense_one_thread", &Tuning::dense_one_thread}, {"dense_form", &Tuning::dense_form},
         {"step_form", &Tuning::step_form}, {"bt_chunks", &Tuning::bt_chunks}, {"bt_warm", &Tuning::bt_warm},
         {"win_shift", &Tuning::win_shift}, {"wave_min_batch", &Tuning::wave_min_batch}, {"wave_two", &Tuning::wave_two},
-        {"bt_fast_rows", &Tuning::bt_fast_rows}, {"wave_history", &Tuning::wave_history}, {"wave_uniform", &Tuning::wave_uniform},
+        {"bt_fast_rows", &Tuning::bt_fast_rows}, {"bt_block_waves", &Tuning::bt_block_waves}, {"wave_history", &Tuning::wave_history}, {"wave_uniform", &Tuning::wave_uniform},
         {"timing", &Tuning::timing},
     };
     for (const auto& e : tab)
@@ -455,6 +456,7 @@ static void bt_args_from_plan(const vit_plan* plan, vit::BtArgs& b) {
     b.c0 = plan->bp.c0;
     b.bt_form = plan->tune.backtrace_form;
     b.no_fast_rows = plan->tune.bt_fast_rows == 1 ? 1 : 0;
+    b.block_waves = plan->tune.bt_block_waves;
     b.lo_affine = plan->bp.lo_affine ? 1 : 0;
     b.lo_off = plan->bp.lo_off;
     for (int d = 0; d < vit::kMaxDenseRows; ++d) b.dense_rows[d] = d < plan->bp.n_dense ? plan->bp.dense_rows[d] : -1;

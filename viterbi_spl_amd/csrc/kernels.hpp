@@ -110,6 +110,7 @@ struct BtArgs {
     const void* logE;       // [B,T,S] the tensor vit_forward decoded (f32 or f16)
     int e_f16;
     int64_t states_stride;  // states of song b start at states + b * states_stride (T; a segment of a checkpointed decode: the whole song's T)
+    int block_waves;        // half back-trace: waves per workgroup (0 / 16 default | 8 | 4: small enough to start beside resident forward waves)
     int no_fast_rows;       // sparse / half back-trace: 1 = every row through the general code (vit_plan_set_option "bt_fast_rows" 1; tests)
     int skip_nonpositive;   // sparse kernel: a song whose lengths[] entry is < 1 is skipped (segments; vit_decode clamps to 1 instead)
     int32_t* counters;      // [B][kBtCounters] per-song event counts of the sparse / half / half-wave kernels (zeroed by vit_backtrace)
