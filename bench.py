@@ -419,6 +419,30 @@ def sweep_row(dec, logA_T, log_pi, E, algo, steps, lengths=None, overlapped=True
     return r
 
 
+def cu_masked_streams(dev):
+    """Two HIP streams on disjoint halves of the chip's compute units (hipExtStreamCreateWithCUMask: CUs 0 .. n/2-1 and n/2 .. n-1),
+    or None where the call is not available.  While one song per workgroup uses at most half the CUs, the forward stream on one half and
+    everything else (emission builder, back-trace, voicing map) on the other keeps the builder's thousands of waves off the CUs that
+    run the latency-bound forward workgroups (pipeline at B = 128: 11.76 -> 11.12 ms per step, scripts/pipeline_cumask.py)."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        words = (n_cus + 31) // 32
+        if words < 2 or n_cus % 64:
+            return None
+        out = []
+        for lo_half in (True, False):
+            mask = [(0xFFFFFFFF if (w < words // 2) == lo_half else 0) for w in range(words)]
+            st = ctypes.c_void_p()
+            if hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), (ctypes.c_uint32 * words)(*mask)) != 0:
+                return None
+            out.append(torch.cuda.ExternalStream(st.value, device=dev))
+        return out
+    except (OSError, AttributeError):
+        return None
+
+
 def packed_row(dec, logA_T, log_pi, T, total_frames, dev, steps, seed=7):
     """A ragged batch as the reference sees it (recordings decoded whole, each with its own T): lengths uniform in [T/4, T], as
     many songs as hold `total_frames` frames, ONE packed [sum T_b, S] emission buffer, vit_decode_packed (forward slots packed
@@ -550,6 +574,9 @@ def pipeline_block(dev, T, steps):
         exact = bool(np.array_equal(st[0][sub].cpu().numpy(), rs)) and bool(np.array_equal(ll[0][sub].cpu().numpy(), rl))
         # overlapped: stream A = forward passes (critical path), stream B = builder of the next step, back-trace + map of the previous one
         sA, sB = torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev)
+        masked = cu_masked_streams(dev) if 2 * B <= torch.cuda.get_device_properties(dev).multi_processor_count else None
+        if masked:                  # the forward workgroups on one half of the chip, builder / back-trace / map on the other
+            sA, sB = masked
         dec.set_option("bt_chunks", dec.chunks_beside_forward(B))
         built = [None, None]
         fwd_done = [None, None]
@@ -590,6 +617,7 @@ def pipeline_block(dev, T, steps):
         out[f"B{B}"] = {"songs": B, "builder_ms": ph[0], "forward_ms": ph[1], "backtrace_ms": ph[2], "voicing_map_ms": ph[3], "one_stream_ms_per_step": total,
                         "Mframes_per_s_one_stream": frames / total / 1e3, "overlapped_ms_per_step": ov, "Mframes_per_s_overlapped": frames / ov / 1e3,
                         "Mframes_per_s_best": frames / min(total, ov) / 1e3, "overlapped_equals_one_stream": same,
+                        "overlapped_streams": "disjoint CU masks (hipExtStreamCreateWithCUMask): forward on one half of the chip, builder / back-trace / map on the other" if masked else "two plain streams",
                         "decode_bit_exact_vs_oracle_on_built_emissions": exact,
                         "builder": {"kernel": "observation_kernel (vit_obs_shaun, spw 5)", "Mframes_per_s": frames / ph[0] / 1e3,
                                     "roofline": {"bound": "hbm", "bytes_per_frame": 360 * 4 + 361 * 4, "achieved": bld_bytes / (ph[0] * 1e-3) / 1e9,
