@@ -267,11 +267,9 @@ struct LaneOut {
 template <int WQ, bool GT, int NWT>
 __global__ void __launch_bounds__(kLnThreads) lane_spec_kernel(BtArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int WX1 = 4 * WQ + kMaxExtras + 1;
     int32_t* loL = reinterpret_cast<int32_t*>(smem);
     float* tabL = reinterpret_cast<float*>(loL + a.SP);
     ln_load_tables<WQ, GT>(a, tabL, loL);
-    (void)WX1;
     const int lane = threadIdx.x & 63;
     const int S = a.S, SD = a.SD;
     const bool packed = a.offsets != nullptr;
