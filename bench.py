@@ -527,8 +527,12 @@ def pipeline_block(dev, T, steps):
     logA_T, log_pi = make_params("tonet", 361, 14)
     dec = ViterbiDecoder(logA_T, log_pi, dev)
     out = {}
-    for B in (128, 1024):
-        X = synth.pitch_logits(min(B, 32), T, 360, seed=5, device=dev)
+    # voicing of the synthetic logits: "toggle" = a voicing switch every other frame (the hardest case for the back-trace: a switch to
+    # the unvoiced state has every voiced source as a candidate, so its row bound fails and the whole row is evaluated); "segments" =
+    # voiced / unvoiced runs of ~120 frames, what a recording looks like
+    for B, voicing in ((128, "toggle"), (1024, "toggle"), (1024, "segments")):
+        key = f"B{B}" if voicing == "toggle" else f"B{B}_voiced_runs"
+        X = synth.pitch_logits(min(B, 32), T, 360, seed=5, device=dev, voicing=voicing)
         if B > 32:
             X = X.repeat(B // 32, 1, 1).contiguous()
         E = [torch.empty((B, T, 361), dtype=torch.float32, device=dev) for _ in range(2)]
@@ -567,6 +571,7 @@ def pipeline_block(dev, T, steps):
         ph = [float(np.mean([e[j].elapsed_time(e[j + 1]) for e in evs])) for j in range(4)]
         total = float(np.mean([e[0].elapsed_time(e[4]) for e in evs]))
         ref_states = st[0].clone()
+        bt_events = {k: round(v * 1000.0 / (B * T), 2) for k, v in dec.backtrace_counters(B, T).items() if k in ("span_misses", "whole_row_evaluations")}
         # parity of the decode inside the pipeline: the oracle on the emission rows the builder produced (three songs)
         from oracle import viterbi_oracle as vo
         sub = [0, min(B, 32) // 2, min(B, 32) - 1]
@@ -614,7 +619,7 @@ def pipeline_block(dev, T, steps):
         dec.set_option("bt_chunks", 0)
         frames = B * T
         bld_bytes = frames * (360 * 4 + 361 * 4)
-        out[f"B{B}"] = {"songs": B, "builder_ms": ph[0], "forward_ms": ph[1], "backtrace_ms": ph[2], "voicing_map_ms": ph[3], "one_stream_ms_per_step": total,
+        out[key] = {"songs": B, "voicing": voicing, "backtrace_events_per_1000_frames": bt_events, "builder_ms": ph[0], "forward_ms": ph[1], "backtrace_ms": ph[2], "voicing_map_ms": ph[3], "one_stream_ms_per_step": total,
                         "Mframes_per_s_one_stream": frames / total / 1e3, "overlapped_ms_per_step": ov, "Mframes_per_s_overlapped": frames / ov / 1e3,
                         "Mframes_per_s_best": frames / min(total, ov) / 1e3, "overlapped_equals_one_stream": same,
                         "overlapped_streams": "disjoint CU masks (hipExtStreamCreateWithCUMask): forward on one half of the chip, builder / back-trace / map on the other" if masked else "two plain streams",
@@ -628,7 +633,7 @@ def pipeline_block(dev, T, steps):
         dec._ws = None
         dec._ws_slots = {}
         torch.cuda.empty_cache()
-    out["workload"] = (f"pitch logits [B, {T}, 360] fp32 resident in HBM (noise floor + melody-like bumps, songs repeat with period 32) -> vit_obs_shaun -> "
+    out["workload"] = (f"pitch logits [B, {T}, 360] fp32 resident in HBM (noise floor + melody-like bumps in the voiced frames, songs repeat with period 32; voicing \"toggle\": two frames of three voiced, \"segments\": runs of ~120 frames) -> vit_obs_shaun -> "
                        f"decode (tonet transition) -> vit_voicing_map; {steps} timed steps")
     return out
 

@@ -211,17 +211,26 @@ def dense_random_log_transition(S: int, seed: int = 0) -> np.ndarray:
     return ((h % 5121).to(torch.float32) * (-1.0 / 256.0)).numpy()
 
 
-def pitch_logits(B: int, T: int, n_bins: int, seed: int = 0, device="cpu") -> torch.Tensor:
+def pitch_logits(B: int, T: int, n_bins: int, seed: int = 0, device="cpu", voicing: str = "toggle") -> torch.Tensor:
     """Synthetic pitch logits ``[B, T, n_bins]`` float32 for the emission builders (bench.py's pipeline block): a weak noise floor
-    (mean -8, sd 1.5: an unvoiced frame) and, in two frames out of three, a melody-like five-bin bump whose centre drifts by a
-    bin or two per frame -- the shape of tests/common.logits_case, generated on the device."""
+    (mean -8, sd 1.5: an unvoiced frame) and, in the voiced frames, a melody-like five-bin bump whose centre drifts by a bin or two
+    per frame -- the shape of tests/common.logits_case, generated on the device.  ``voicing``: "toggle" = two frames out of three are
+    voiced (a voicing switch every other frame: the hardest case for the back-trace's row bound); "segments" = voiced and unvoiced
+    runs of ~120 frames on average (a two-state chain that flips with probability 1/120 per frame: what a recording looks like)."""
     g = torch.Generator(device=device)
     g.manual_seed(1000003 * seed + 17)
     x = torch.randn((B, T, n_bins), generator=g, device=device) * 1.5 - 8.0
     steps = torch.randint(-2, 3, (B, T), generator=g, device=device)
     centre = (n_bins // 2 + torch.cumsum(steps, dim=1)) % (n_bins - 16) + 8
     amp = torch.rand((B, T), generator=g, device=device) * 2.0 + 0.5
-    voiced = (torch.arange(T, device=device) % 3 != 0).to(x.dtype)[None, :] * amp
+    if voicing == "segments":
+        flips = (torch.rand((B, T), generator=g, device=device) < 1.0 / 120.0).to(torch.int32)
+        on = ((torch.cumsum(flips, dim=1) + torch.arange(B, device=device)[:, None]) % 2 == 0).to(x.dtype)
+    elif voicing == "toggle":
+        on = (torch.arange(T, device=device) % 3 != 0).to(x.dtype)[None, :]
+    else:
+        raise ValueError("voicing must be 'toggle' or 'segments'")
+    voiced = on * amp
     shape = torch.tensor([1.0, 3.0, 6.0, 3.0, 1.0], device=device)
     for k in range(5):
         x.scatter_add_(2, (centre + (k - 2)).unsqueeze(-1), (voiced * shape[k]).unsqueeze(-1))
