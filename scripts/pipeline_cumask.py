@@ -43,13 +43,43 @@ layouts = {
     "alternating bits": ([0x55555555] * 8, [0xAAAAAAAA] * 8),
     "first four / last four words": ([0xFFFFFFFF] * 4 + [0] * 4, [0] * 4 + [0xFFFFFFFF] * 4),
     "forward everywhere, builder on the high halves": (ALL, [0xFFFF0000] * 8),
+    "first four words / last two words (64 CUs)": ([0xFFFFFFFF] * 4 + [0] * 4, [0] * 6 + [0xFFFFFFFF] * 2),
+    "first four words / last word (32 CUs)": ([0xFFFFFFFF] * 4 + [0] * 4, [0] * 7 + [0xFFFFFFFF]),
+    # three streams: the builder throttled to a few CUs so that its HBM traffic spreads over the whole forward pass
+    "three streams: forward 4 words / back-trace 3 words / builder 1 word": ([0xFFFFFFFF] * 4 + [0] * 4, [0] * 4 + [0xFFFFFFFF] * 3 + [0], [0] * 7 + [0xFFFFFFFF]),
+    "three streams: forward 4 words / back-trace 2 words / builder 2 words": ([0xFFFFFFFF] * 4 + [0] * 4, [0] * 4 + [0xFFFFFFFF] * 2 + [0] * 2, [0] * 6 + [0xFFFFFFFF] * 2),
 }
 for chunks in (dec.chunks_beside_forward(B), 0):
-    for name, (mf, mb) in layouts.items():
+    for name, masks in layouts.items():
+        mf, mb = masks[0], masks[1]
         sA = masked_stream(mf) if mf else torch.cuda.Stream(device=dev, priority=-1)
         sB = masked_stream(mb) if mb else torch.cuda.Stream(device=dev)
+        sC = masked_stream(masks[2]) if len(masks) > 2 else None
         dec.set_option("bt_chunks", chunks)
-        built, fwd_done = [None, None], [None, None]
+        built, fwd_done, bt_done = [None, None], [None, None], [None, None]
+
+        def run3(n):
+            with torch.cuda.stream(sC):
+                emissions.shaun_log_emissions(X, out=E[0])
+                built[0] = torch.cuda.Event(); built[0].record()
+            for i in range(n):
+                k = i & 1
+                with torch.cuda.stream(sA):
+                    sA.wait_event(built[k])
+                    if bt_done[k] is not None: sA.wait_event(bt_done[k])          # workspace slot k is free
+                    dec.decode_into(E[k], st[k], ll[k], algo="banded", phase="forward", slot=k)
+                    fwd_done[k] = torch.cuda.Event(); fwd_done[k].record()
+                if i + 1 < n:
+                    with torch.cuda.stream(sC):
+                        if fwd_done[k ^ 1] is not None: sC.wait_event(fwd_done[k ^ 1])   # forward i - 1 has read E[k ^ 1]
+                        emissions.shaun_log_emissions(X, out=E[k ^ 1])
+                        built[k ^ 1] = torch.cuda.Event(); built[k ^ 1].record()
+                with torch.cuda.stream(sB):
+                    sB.wait_event(fwd_done[k])
+                    dec.decode_into(E[k], st[k], ll[k], algo="banded", phase="backtrace", slot=k)
+                    assert lib.vit_voicing_map(st[k].data_ptr(), st[k].numel(), 360, voiced.data_ptr(), bins.data_ptr(), torch.cuda.current_stream(dev).cuda_stream) == 0
+                    bt_done[k] = torch.cuda.Event(); bt_done[k].record()
+            torch.cuda.synchronize()
 
         def run(n):
             with torch.cuda.stream(sB):
@@ -70,7 +100,10 @@ for chunks in (dec.chunks_beside_forward(B), 0):
                     assert lib.vit_voicing_map(st[k].data_ptr(), st[k].numel(), 360, voiced.data_ptr(), bins.data_ptr(), torch.cuda.current_stream(dev).cuda_stream) == 0
             torch.cuda.synchronize()
 
+        if sC is not None:
+            run = run3
         run(2)
+        built, fwd_done, bt_done = [built[0], built[1]], [None, None], [None, None]
         t0 = time.perf_counter()
         run(10)
         ms = (time.perf_counter() - t0) / 10 * 1e3
