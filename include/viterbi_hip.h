@@ -115,7 +115,9 @@ int vit_plan_query(const vit_plan *plan, vit_plan_info *info);
  *   "bt_block_waves"   half history's back-trace: waves per workgroup, 0 = 16 | 8 | 4.  Eight-wave workgroups (208 registers per SIMD) can start
  *                      on a CU whose SIMDs each hold one 256-register forward wave, i.e. beside the next batch's forward pass at up to
  *                      4 x CUs songs in flight (the two-stream schedule); sixteen-wave ones cannot
- *   "win_shift"        LDS window shift 0..3 (-1 from the plan); "wave_min_batch" (0 default), "wave_two" 1
+ *   "win_shift"        LDS window shift 0..3 (-1 from the plan); "wave_min_batch" (0 default), "wave_two" 1 | 2 (register budget of
+ *                      the wave kernel) + 4 = a full-history row carries its own scalars only (default: also those of the two frames
+ *                      before it, so that the back-trace touches one scalar line per three frames; A/B and tests)
  *   "wave_history"     wave form: 0 / 1 = store every delta row | 2 = store the rows of even frames only (the back-trace rebuilds
  *                      the 32 values an odd frame needs from the row before it and the emissions): half the workspace and a
  *                      faster forward pass for a slower back-trace; VIT_EUNSUPPORTED where the plan does not

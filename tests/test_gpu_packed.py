@@ -274,3 +274,37 @@ def test_half_backtrace_with_small_workgroups(golden, dev):
             st, ll = dec.decode(E, lengths=lens, algo="wave", out_dtype=torch.int32)
             assert np.array_equal(st.cpu().numpy(), ref_s) and np.array_equal(ll.cpu().numpy(), ref_l), (waves, chunks, warm)
     dec.set_option("reset", 0)
+
+
+@pytest.mark.parametrize("name", ["tonet361", "msnet321"])
+def test_scalars_of_three_frames_per_history_row(golden, dev, name):
+    """Full history of the wave form with one extra column: row t carries the scalars (frame maximum, delta of the extra column) of
+    frames t, t-1, t-2, and the back-trace kernels read frame t's from the carrier row t - t % 3 + 2, or from the song's last row
+    (csrc/kernels.hpp wave_aux_frames / wave_aux_row).  Every song length 1 .. 13 (all residues, the clamp at the last row), chunk
+    boundaries at every position, both back-trace kernels and the packed decode -- against the oracle, and against the layout in
+    which a row carries its own scalars only ("wave_two" bit 2)."""
+    A, pi = golden["params"][f"{name}_logA_T"], golden["params"][f"{name}_log_pi"]
+    dec = ViterbiDecoder(A, pi, dev)
+    S = dec.S
+    lens = np.array(list(range(1, 14)) + [97, 98, 99, 100], np.int64)
+    B, T = len(lens), 100
+    for kind, gen in (("peaks", synth.emissions_peaks), ("ties", synth.emissions_ties)):
+        E = gen(B, T, S, seed=31, device=dev)
+        ref_s, ref_l = vo.decode_c(A, pi, E.cpu().numpy(), lengths=lens)
+        for own_only in (0, 4):
+            for form, chunks, warm in ((0, 0, -1), (0, 7, 0), (0, 32, 1), (4, 0, -1), (4, 5, 0), (4, 64, 2), (4, 13, 1)):
+                dec.set_option("reset", 0)
+                dec.set_option("wave_two", own_only)
+                dec.set_option("backtrace_form", form)
+                dec.set_option("bt_chunks", chunks)
+                dec.set_option("bt_warm", warm)
+                st, ll = dec.decode(E, lengths=torch.from_numpy(lens).to(dev), algo="wave", out_dtype=torch.int32)
+                assert np.array_equal(st.cpu().numpy(), ref_s), (name, kind, own_only, form, chunks, warm)
+                assert np.array_equal(ll.cpu().numpy(), ref_l)
+            dec.set_option("reset", 0)
+            dec.set_option("wave_two", own_only)
+            Ep, off = _pack(E, lens)
+            st, ll = dec.decode_packed(Ep, off, out_dtype=torch.int32)
+            assert np.array_equal(_unpack(st.cpu().numpy(), off, T), ref_s), (name, kind, own_only, "packed")
+            assert np.array_equal(ll.cpu().numpy(), ref_l)
+    dec.set_option("reset", 0)

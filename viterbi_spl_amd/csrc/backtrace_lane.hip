@@ -66,6 +66,11 @@ __device__ __forceinline__ const float* ln_readlane_ptr(const float* p, int l) {
     const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, l), hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
     return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
 }
+// the scalars of frame t (frame maximum, then delta of the extra columns at + xcol0 - mcol): in row t, or in its carrier row
+__device__ __forceinline__ const float* ln_aux(const BtArgs& a, const float* __restrict__ hist, const int t, const int last) {
+    const int ta = a.aux_frames == 3 ? wave_aux_row(t, last < 0 ? 0 : last) : t;
+    return hist + (size_t)ta * a.SD + a.mcol + 2 * (ta - t);
+}
 __device__ __forceinline__ void ln_chunk_bounds(int Lf, int c, int C, int& lo_c, int& hi_c) {
     lo_c = (int)((long long)Lf * c / C);
     hi_c = (int)((long long)Lf * (c + 1) / C);
@@ -125,7 +130,8 @@ struct LaneDecider {
         return idx == 0x7fffffffu ? 0 : (int)idx;                            // an all -inf frame resolves to index 0 like np.argmax
     }
 
-    __device__ __forceinline__ bool step(const float* __restrict__ row, const int cur, const bool act, int& nxt) {
+    // aux: where the scalars of this frame sit -- &row[mcol], or (BtArgs::aux_frames == 3) the same slot of the frame in its carrier row
+    __device__ __forceinline__ bool step(const float* __restrict__ row, const float* __restrict__ aux, const int cur, const bool act, int& nxt) {
         constexpr int W = 4 * WQ, WX1 = W + kMaxExtras + 1;
         const int S = a.S, nx = a.n_extras;
         int lo;
@@ -152,10 +158,10 @@ struct LaneDecider {
         f32x4_u dv[WQ];
 #pragma unroll
         for (int q = 0; q < WQ; ++q) dv[q] = *reinterpret_cast<const f32x4_u*>(dp + 4 * q);
-        const float Mt = row[a.mcol];
+        const float Mt = aux[0];
         float dx[kMaxExtras];
 #pragma unroll
-        for (int k = 0; k < kMaxExtras; ++k) dx[k] = k < nx ? row[a.xcol0 >= 0 ? a.xcol0 + k : a.col0 + a.extras[k]] : 0.f;
+        for (int k = 0; k < kMaxExtras; ++k) dx[k] = k < nx ? (a.xcol0 >= 0 ? aux[a.xcol0 - a.mcol + k] : row[a.col0 + a.extras[k]]) : 0.f;
         float m = -INFINITY;
         int arg = kLnBig;
         float cj;
@@ -331,9 +337,10 @@ __global__ void __launch_bounds__(kLnThreads) lane_spec_kernel(BtArgs a) {
     int t = act ? top : 0;
     int entry_v = cur;                      // the state this chunk assumed at frame hi_c (no warm-up: what it started from)
     while (__any(act)) {
-        const float* __restrict__ row = hist + (size_t)(t < 0 ? 0 : t) * SD;
+        const int tr = t < 0 ? 0 : t;
+        const float* __restrict__ row = hist + (size_t)tr * SD;
         int nxt;
-        if (decide.step(row, cur, act, nxt)) {
+        if (decide.step(row, ln_aux(a, hist, tr, Lf), cur, act, nxt)) {
             if (t >= hi_c) { if (t == hi_c) entry_v = nxt; }
             else out.push(states, t, nxt);
             cur = nxt;
@@ -446,9 +453,10 @@ __global__ void __launch_bounds__(kLnThreads) lane_repair_kernel(BtArgs a, const
             }
         }
         const bool act = repairing && !done;
-        const float* __restrict__ row = hist + (size_t)(act ? t : 0) * SD;
+        const int tr = act ? t : 0;
+        const float* __restrict__ row = hist + (size_t)tr * SD;
         int nxt;
-        if (decide.step(row, cur, act, nxt)) {
+        if (decide.step(row, ln_aux(a, hist, tr, Lf), cur, act, nxt)) {
             const int old = states[t];
             states[t] = nxt;
             ++n_repf;

@@ -174,7 +174,9 @@ __global__ void __launch_bounds__(1024) sparse_backtrace_kernel(BtArgs a) {
                 for (int h = 0; h < 2; ++h) {
                     int r = (lane >> 3) + 8 * h;
                     r = r < rows ? r : rows - 1;
-                    auxv[h] = hist[(size_t)(first + r) * SD + aux_col];
+                    // (aux_frames == 3: the scalars of frame t from its carrier row -- one line per three frames)
+                    const int t = first + r, ta = a.aux_frames == 3 ? wave_aux_row(t, Tb - 1) : t;
+                    auxv[h] = hist[(size_t)ta * SD + aux_col + 2 * (ta - t)];
                 }
 #pragma unroll
                 for (int v = 0; v < kSpVec; ++v) {

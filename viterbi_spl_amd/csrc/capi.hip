@@ -46,7 +46,7 @@ struct FwdStamp {
     const void* ws = nullptr;
     int64_t B = 0, T = 0;
     int family = 0;            // 1 dense / step, 2 banded (one song per workgroup), 3 wave
-    int SD = 0, col0 = 0, mcol = 0, xcol0 = -1;
+    int SD = 0, col0 = 0, mcol = 0, xcol0 = -1, aux_frames = 1;
     int have_fmax = 0;         // column mcol of every history row holds a bound on max_i delta_t[i]
     int half = 0;              // wave form, even rows only: the back-trace re-reads the emissions
     const void* logE = nullptr;
@@ -361,7 +361,7 @@ static void fwd_args_from_plan(const vit_plan* plan, vit::FwdArgs& a) {
     a.wave_npl = plan->bp.wave_npl;
     a.wave_dk = plan->bp.wave_dk;
     a.wave_u5 = tn.wave_uniform == 1 ? 0 : (tn.wave_uniform == 2 ? (plan->wave_u5 >= 1 ? 1 : 0) : (tn.wave_uniform == 3 && plan->wave_u5 == 2 ? 3 : plan->wave_u5));
-    a.wave_flags = tn.wave_two == 1 ? 1 : (tn.wave_two == 2 ? 2 : 0);
+    a.wave_flags = ((tn.wave_two & 3) == 1 ? 1 : ((tn.wave_two & 3) == 2 ? 2 : 0)) | (tn.wave_two & 4);   // (bit 2: a row carries its own scalars only -- A/B)
     a.win_shift = (plan->bp.ok && plan->bp.lo_affine) ? (plan->bp.lo_off & 3) : 0;
     a.win_shift2 = (plan->bp.ok && plan->bp.pair_ok && plan->bp.lo2_affine) ? (plan->bp.lo2_off & 3) : 0;
     if (tn.win_shift >= 0) a.win_shift = a.win_shift2 = tn.win_shift & 3;   // every value is functionally correct
@@ -424,6 +424,7 @@ int vit_forward(const vit_plan* plan, const void* logE, int emis_dtype, int64_t 
         st.col0 = st.SD - plan->S;
         st.mcol = 0;
         st.xcol0 = 1;
+        st.aux_frames = half || (a.wave_flags & 4) ? 1 : vit::wave_aux_frames(plan->bp.wave_npl, plan->S, a.n_extras);
         st.have_fmax = 1;
         st.half = half ? 1 : 0;
         e = vit::launch_wave(a, emis_dtype == VIT_F16, (hipStream_t)stream);
@@ -527,6 +528,7 @@ static int backtrace_impl(const vit_plan* plan, const void* logE, int emis_dtype
     b.col0 = st.col0;
     b.mcol = st.mcol;
     b.xcol0 = st.xcol0;
+    b.aux_frames = st.aux_frames;
     b.have_fmax = st.have_fmax;
     b.states_stride = T;
     if (st.family == 3 && !(b.banded && b.n_dense == 0)) return VIT_EINVAL;   // (cannot happen: wave_ok implies both)
@@ -679,6 +681,7 @@ int vit_decode_checkpointed(const vit_plan* plan, const void* logE, int emis_dty
     b.col0 = SDW - plan->S;
     b.mcol = 0;
     b.xcol0 = 1;
+    b.aux_frames = 1;       // (a segment's sub-problem ends one frame behind the rows its forward pass wrote: every frame's scalars from its own row)
     b.have_fmax = 1;
     b.hist = reinterpret_cast<const float*>(ws + c.off_seg);
     b.hist_rows = K + 1;
@@ -897,6 +900,7 @@ int vit_decode_packed(const vit_plan* plan, const void* logE, int emis_dtype, in
     b.col0 = b.SD - plan->S;
     b.mcol = 0;
     b.xcol0 = 1;
+    b.aux_frames = (a.wave_flags & 4) ? 1 : vit::wave_aux_frames(plan->bp.wave_npl, plan->S, b.n_extras);
     b.have_fmax = 1;
     b.hist = reinterpret_cast<const float*>(ws + k.off_hist);
     b.hist_rows = 0;

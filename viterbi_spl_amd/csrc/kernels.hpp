@@ -90,6 +90,9 @@ struct BtArgs {
     int T, S, SP, SD, W, K;
     int col0, mcol;         // history row layout: state i in column col0 + i, the frame maximum in column mcol
     int xcol0;              // >= 0: column xcol0 + k holds a copy of delta of extra column k (next to the frame maximum); -1: none
+    int aux_frames;         // 1, or 3 (wave form with every row stored and one extra column, wave_aux_frames): row t also carries the scalars of
+                            // frames t-1 and t-2, at columns mcol + 2k / xcol0 + 2k -- the back-trace reads the scalars of frame t from the
+                            // carrier row wave_aux_row(t, last row) and touches one scalar line per three frames instead of one per frame
     int chunks, warm;       // time-parallel back-trace: chunks per song, warm-up frames
     int banded;             // 1: row structure (window / c0 / extras / dense rows) proven by the plan
     int have_fmax;          // the forward pass was a banded kernel (it fills pad column S of the history rows)
@@ -135,6 +138,10 @@ hipError_t launch_segment_prep(const int64_t* lengths, int64_t B, int T, int s0,
 // history layout of the wave form: row stride 64*npl floats, state i in column 64*npl - S + i, the frame maximum in column 0,
 // a copy of delta of extra column k in column 1 + k
 constexpr int wave_hist_stride(int npl) { return 64 * npl; }
+// frames whose scalars a full-history row of the wave form carries in lane 0's idle slots (the row's own and the two before it)
+constexpr int wave_aux_frames(int npl, int S, int n_extras) { return n_extras == 1 && npl >= 6 && 64 * npl - S >= 6 ? 3 : 1; }   // (six idle slots)
+// the row the back-trace takes the scalars of frame t from: the next row with t % 3 == 2, or the last row written
+__host__ __device__ constexpr int wave_aux_row(int t, int last) { return t - t % 3 + 2 < last ? t - t % 3 + 2 : last; }
 hipError_t launch_backtrace(BtArgs a, hipStream_t st);
 // backtrace_sparse.hip: fetches only the span of each history row around the path (banded plans, candidates on one lane)
 bool sparse_backtrace_applies(const BtArgs& a);

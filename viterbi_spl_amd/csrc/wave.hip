@@ -131,7 +131,9 @@ __device__ __forceinline__ void store_row(float* __restrict__ p, const float (&d
 // that, a lane's NPL emission columns are one unconditional vector load at E_row + NPL*lane - o -- for the leading
 // lanes that reaches back into the previous row of the SAME tensor (rows >= 1 only: row 0 is loaded element-wise), never
 // out of bounds -- and the history row is stored in slot order: row stride 64*NPL floats, state i in column o + i, and
-// M_t = max_i delta_t[i] in column 0, a copy of delta_t of extra column x in column 1 + x (idle slots).  No branch surrounds a memory instruction, so the in-order vmcnt
+// M_t = max_i delta_t[i] in column 0, a copy of delta_t of extra column x in column 1 + x (idle slots) -- and, with one extra column and six idle
+// slots (A3), the same two scalars of frames t-1 and t-2 in columns 2 3 | 4 5: they are still in scalar registers, four more selects per frame,
+// and the back-trace kernels then find the scalars of three frames in ONE line (the carrier row t - t % 3 + 2; B = 2048: -8 % / -13 %).  No branch surrounds a memory instruction, so the in-order vmcnt
 // of the emission prefetch is exact.  The back-trace is told the column offset and the column of M (BtArgs::col0, mcol).
 //
 // HM (history mode).  0: every delta row is stored (row t of a song at hist + t * 64*NPL).  1: only the rows of EVEN frames are
@@ -168,6 +170,9 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
     static_assert(UV < 2 || NPL == 6, "uniform-lane forms: six states per lane");
     constexpr bool U5 = UV == 2, U3 = UV == 3;
     constexpr bool PK = HM == 7;               // packed batch: this wave is a SLOT that walks a list of songs back to back
+    // every row stored, one extra column: row t carries the scalars of frames t, t-1 and t-2 (columns 0 1 | 2 3 | 4 5 of lane 0), so that
+    // the back-trace finds the scalars of three frames in ONE line (kernels.hpp wave_aux_frames / wave_aux_row)
+    constexpr bool A3 = (HM == 0 || HM == 6 || HM == 7) && NX == 1 && NPL >= 6;      // (and six idle slots: run time, l0a below)
     const int S = a.S;
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -175,6 +180,7 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
     // ---------------- per-lane constants
     const int o = SDW - S;                                 // idle leading slots (>= 1)
     const int j0 = NPL * lane - o;                         // state of slot 0 of this lane (negative: idle)
+    const bool l0a = A3 && lane == 0 && wave_aux_frames(NPL, S, NX) == 3 && !(a.wave_flags & 4);   // this lane's slots 2 .. 5 carry the scalars of frames t-1, t-2
     f32x2 aw[NPL][NPM];
     {
         const float* __restrict__ tv = reinterpret_cast<const float*>(a.image + a.off_tabV);
@@ -231,13 +237,19 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
     // copy of delta_t of the extra columns, so that the sparse back-trace finds its per-row scalars in ONE cache line
     // (HM 1: row t/2 of an even frame t; Mp / xp = the scalars of frame t-1, slots 1+NX .. 1+2*NX)
     auto store_hist = [&](const int t, const float (&d)[NPL], const float M, const float (&xd)[NX > 0 ? NX : 1], const float Mp,
-                          const float (&xp)[NX > 0 ? NX : 1]) {
+                          const float (&xp)[NX > 0 ? NX : 1], const float Mq, const float xq) {
         float v[NPL];
 #pragma unroll
         for (int k = 0; k < NPL; ++k) v[k] = d[k];
         v[0] = lane == 0 ? M : v[0];
 #pragma unroll
         for (int x = 0; x < NX; ++x) v[1 + x] = lane == 0 ? xd[x] : v[1 + x];
+        if (A3) {
+            v[2] = l0a ? Mp : v[2];
+            v[3] = l0a ? xp[0] : v[3];
+            v[4] = l0a ? Mq : v[4];
+            v[5] = l0a ? xq : v[5];
+        }
         if (HM == 1) {
             v[1 + NX] = lane == 0 ? Mp : v[1 + NX];
 #pragma unroll
@@ -285,7 +297,8 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
     float M = frame_max(d);
     float xd[NX > 0 ? NX : 1] = {};
     extra_deltas(d, xd);
-    if (t0 == 0) store_hist(0, d, M, xd, M, xd);
+    if (t0 == 0) store_hist(0, d, M, xd, M, xd, M, xd[0]);
+    float Mb = M, xb = xd[0];                  // (A3) the scalars of the frame before the previous one
     const int t1 = t0 == 0 ? 1 : t0;           // first frame the loop computes
 
     float er[PF][NPL];
@@ -360,7 +373,8 @@ __global__ void __launch_bounds__(256, WPS) wave_forward_kernel(FwdArgs a) {
         for (int x = 0; x < (NX > 0 ? NX : 1); ++x) xp[x] = xd[x];
         M = frame_max(d);
         extra_deltas(d, xd);               // for the next frame's candidates, and for the history row
-        if (decltype(stored)::value && HM != 2 && HM != 4) store_hist(t, d, M, xd, Mp, xp);
+        if (decltype(stored)::value && HM != 2 && HM != 4) store_hist(t, d, M, xd, Mp, xp, Mb, xb);
+        if (A3) { Mb = Mp; xb = xp[0]; }
         if (HM != 3 && HM != 4) load_row(t + PF < Tb ? t + PF : Tb - 1, e);     // (HM 2 / 3 / 4: timing builds only -- no stores / no loads / neither)
     };
     // The loop body is a whole number of frame pairs when only even frames are stored: t is odd at its top, frame t + q is
