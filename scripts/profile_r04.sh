@@ -55,9 +55,6 @@ PY
 if [ -n "$ONLY_PMC" ]; then
     for part in $ONLY_PMC; do pmc $part $part; done     # e.g. ONLY_PMC="configs4" scripts/profile_r04.sh
 else
-    pmc obs obs
-    pmc lane lane
-    pmc b1024 b1024
-    pmc configs4 configs4
+    for part in ${PMC_PARTS-obs lane b1024 configs4}; do pmc $part $part; done      # PMC_PARTS="lane b1024": only those after the kernel stats
 fi
 ls -la $OUT
