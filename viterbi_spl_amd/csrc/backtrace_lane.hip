@@ -32,6 +32,7 @@ namespace vit {
 namespace {
 
 typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
 typedef int i32x4_u __attribute__((ext_vector_type(4), aligned(4)));
 
 constexpr int kLnBig = 0x7fffffff;
@@ -66,11 +67,6 @@ __device__ __forceinline__ const float* ln_readlane_ptr(const float* p, int l) {
     const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, l), hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
     return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
 }
-// the scalars of frame t (frame maximum, then delta of the extra columns at + xcol0 - mcol): in row t, or in its carrier row
-__device__ __forceinline__ const float* ln_aux(const BtArgs& a, const float* __restrict__ hist, const int t, const int last) {
-    const int ta = a.aux_frames == 3 ? wave_aux_row(t, last < 0 ? 0 : last) : t;
-    return hist + (size_t)ta * a.SD + a.mcol + 2 * (ta - t);
-}
 __device__ __forceinline__ void ln_chunk_bounds(int Lf, int c, int C, int& lo_c, int& hi_c) {
     lo_c = (int)((long long)Lf * c / C);
     hi_c = (int)((long long)Lf * (c + 1) / C);
@@ -95,6 +91,10 @@ struct LaneDecider {
     bool pend = false;        // this lane's frame waits for the full evaluation
     float m_p = 0.f;          // the pending frame's maximum over the window / extra-column candidates ...
     int arg_p = 0;            // ... and the lowest index that attains it
+    // BtArgs::aux_frames == 3: a carrier row holds the scalars of three frames (kernels.hpp wave_aux_row); the lane keeps the six
+    // values of the carrier row it last read, so that the scalar line is fetched once per three frames
+    float q[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int qrow = -1;
 
     __device__ __forceinline__ void init() {
 #pragma unroll
@@ -130,8 +130,8 @@ struct LaneDecider {
         return idx == 0x7fffffffu ? 0 : (int)idx;                            // an all -inf frame resolves to index 0 like np.argmax
     }
 
-    // aux: where the scalars of this frame sit -- &row[mcol], or (BtArgs::aux_frames == 3) the same slot of the frame in its carrier row
-    __device__ __forceinline__ bool step(const float* __restrict__ row, const float* __restrict__ aux, const int cur, const bool act, int& nxt) {
+    // row = delta row t of this lane's song (hist + t * SD); last = the song's last row
+    __device__ __forceinline__ bool step(const float* __restrict__ row, const int t, const int last, const int cur, const bool act, int& nxt) {
         constexpr int W = 4 * WQ, WX1 = W + kMaxExtras + 1;
         const int S = a.S, nx = a.n_extras;
         int lo;
@@ -158,10 +158,26 @@ struct LaneDecider {
         f32x4_u dv[WQ];
 #pragma unroll
         for (int q = 0; q < WQ; ++q) dv[q] = *reinterpret_cast<const f32x4_u*>(dp + 4 * q);
-        const float Mt = aux[0];
+        float Mt;
         float dx[kMaxExtras];
+        if (a.aux_frames == 3) {                      // (one extra column; mcol = 0, xcol0 = 1: columns 2k, 2k + 1 of the carrier row hold frame ta - k)
+            const int ta = wave_aux_row(t, last < 0 ? 0 : last), kf = ta - t;
+            if (ta != qrow) {
+                const float* __restrict__ ar = row + (ptrdiff_t)kf * a.SD + a.mcol;
+                const f32x4_u qa = *reinterpret_cast<const f32x4_u*>(ar);
+                const f32x2_u qb = *reinterpret_cast<const f32x2_u*>(ar + 4);
+                q[0] = qa.x; q[1] = qa.y; q[2] = qa.z; q[3] = qa.w; q[4] = qb.x; q[5] = qb.y;
+                qrow = ta;
+            }
+            Mt = kf == 0 ? q[0] : (kf == 1 ? q[2] : q[4]);
 #pragma unroll
-        for (int k = 0; k < kMaxExtras; ++k) dx[k] = k < nx ? (a.xcol0 >= 0 ? aux[a.xcol0 - a.mcol + k] : row[a.col0 + a.extras[k]]) : 0.f;
+            for (int k = 0; k < kMaxExtras; ++k) dx[k] = 0.f;
+            dx[0] = kf == 0 ? q[1] : (kf == 1 ? q[3] : q[5]);
+        } else {
+            Mt = row[a.mcol];
+#pragma unroll
+            for (int k = 0; k < kMaxExtras; ++k) dx[k] = k < nx ? row[a.xcol0 >= 0 ? a.xcol0 + k : a.col0 + a.extras[k]] : 0.f;
+        }
         float m = -INFINITY;
         int arg = kLnBig;
         float cj;
@@ -340,7 +356,7 @@ __global__ void __launch_bounds__(kLnThreads) lane_spec_kernel(BtArgs a) {
         const int tr = t < 0 ? 0 : t;
         const float* __restrict__ row = hist + (size_t)tr * SD;
         int nxt;
-        if (decide.step(row, ln_aux(a, hist, tr, Lf), cur, act, nxt)) {
+        if (decide.step(row, tr, Lf, cur, act, nxt)) {
             if (t >= hi_c) { if (t == hi_c) entry_v = nxt; }
             else out.push(states, t, nxt);
             cur = nxt;
@@ -456,7 +472,7 @@ __global__ void __launch_bounds__(kLnThreads) lane_repair_kernel(BtArgs a, const
         const int tr = act ? t : 0;
         const float* __restrict__ row = hist + (size_t)tr * SD;
         int nxt;
-        if (decide.step(row, ln_aux(a, hist, tr, Lf), cur, act, nxt)) {
+        if (decide.step(row, tr, Lf, cur, act, nxt)) {
             const int old = states[t];
             states[t] = nxt;
             ++n_repf;
